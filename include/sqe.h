@@ -1,0 +1,185 @@
+/* sqe.h -- C ABI of libsqe.so, the MI355X (gfx950) embedding + cosine k-NN + cosine-cache
+ * engine that replaces the Ollama-embed / OpenSearch-HNSW / Redis-scan leg of the
+ * reference's /ask pipeline (/root/reference/app/main.py:56-180, 250-373).
+ *
+ * The reference has no FFI of its own: its hot path is three network clients called by
+ * plain Python names.  Each entry point below states which reference call it stands
+ * behind; INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - return 0 (SQE_OK) or a negative error code; sqe_last_error() gives thread-local text
+ *   - the caller allocates every output buffer; the library owns all device memory
+ *   - host inputs are copied before return and never retained
+ *   - "_device" variants take device pointers, enqueue on the context stream and do not
+ *     synchronise (sqe_synchronize does); they exist so a caller that already holds its
+ *     data in HBM (bench.py, the encoder -> search hand-off, torch.distributed shards)
+ *     pays no PCIe copy
+ *   - every entry point is thread-safe: the reference calls add_embeddings from a
+ *     thread-pool thread while search runs on the event-loop thread (main.py:454-455, 499)
+ *   - one context drives ONE device; multi-GPU = one process per GPU (torch.distributed)
+ */
+#ifndef SQE_H
+#define SQE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQE_VERSION 100 /* 0.1.0 */
+
+typedef struct sqe_ctx sqe_ctx;
+typedef struct sqe_index sqe_index;
+typedef struct sqe_cache sqe_cache;
+typedef struct sqe_encoder sqe_encoder;
+
+enum {
+    SQE_OK = 0,
+    SQE_ERR_INVALID = -1,     /* bad argument */
+    SQE_ERR_HIP = -2,         /* a HIP runtime call failed */
+    SQE_ERR_OOM = -3,         /* device or host allocation failed */
+    SQE_ERR_STATE = -4,       /* object not in a state that allows the call */
+    SQE_ERR_UNSUPPORTED = -5  /* valid request this build does not implement */
+};
+
+enum { SQE_INDEX_FLAT = 0, SQE_INDEX_IVF_FLAT = 1 };
+
+/* How the stored rows are scanned.  Both return exact fp32 cosines of the returned ids.
+ *   BF16_RESCORE: bf16 MFMA scan keeps the best `rescore_k` per query, which are then
+ *                 re-scored in fp32 from the fp32 master copy (default);
+ *   FP32:         fp32 MFMA scan of the master copy (exact ordering by construction). */
+enum { SQE_SCAN_BF16_RESCORE = 0, SQE_SCAN_FP32 = 1 };
+
+/* ---- library / context ---------------------------------------------------------- */
+int sqe_version(void);
+const char* sqe_last_error(void);
+
+/* device_ids[0] is the HIP device this context drives (n_dev must be 1). */
+int sqe_create(const int* device_ids, int n_dev, sqe_ctx** out);
+void sqe_destroy(sqe_ctx* ctx);
+int sqe_synchronize(sqe_ctx* ctx);
+/* hipStream_t the "_device" entry points enqueue on (for event timing by the caller). */
+void* sqe_stream(sqe_ctx* ctx);
+int sqe_device_info(sqe_ctx* ctx, char* name, int name_cap, int* cu_count, int64_t* hbm_bytes);
+
+/* ---- vector index: stands behind OpenSearchIndexer (main.py:291-373) ------------- */
+/* Index mapping of main.py:262-282: cosine similarity over `dim`-d vectors.  `kind`
+ * selects exact brute force (FLAT) or IVF-flat with `nlist` lists. dim % 64 == 0. */
+int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out);
+void sqe_index_destroy(sqe_index* idx);
+int sqe_index_reserve(sqe_index* idx, int64_t rows);
+
+/* add_embeddings (main.py:309-338): L2-normalises each row as x / (||x|| + 1e-9) in fp32
+ * (main.py:315-316) and appends; rows get ids count .. count+n-1.  x is [n, dim] row-major. */
+int sqe_index_add(sqe_index* idx, const float* x_host, int64_t n);
+int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n);
+/* Re-indexing an existing `_id` overwrites the document (OpenSearch "index" op,
+ * main.py:321-325): replace the given rows in place. */
+int sqe_index_update(sqe_index* idx, const int64_t* rows_host, const float* x_host, int64_t n);
+/* has_any_data (main.py:300-307) is count > 0. */
+int sqe_index_count(const sqe_index* idx, int64_t* out);
+/* Normalised fp32 rows as stored (`_source.embedding` of a hit, main.py:327-331). */
+int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, float* out_host);
+
+/* Options: "scan_mode" (SQE_SCAN_*), "rescore_k" (candidates kept by the bf16 scan,
+ * 0 = automatic), "nprobe" default for IVF. */
+int sqe_index_set_option(sqe_index* idx, const char* key, double value);
+
+/* search (main.py:347-373): q is [B, dim] row-major raw query embeddings; each is
+ * normalised as q / (||q|| + 1e-9) (main.py:353-354) and its cosine top-k returned best
+ * first, ties to the lowest id.  cos_out [B,k] fp32 cosines, id_out [B,k] int64 row ids,
+ * padded with (-inf, -1) when fewer than k rows qualify.  The reference searches row 0
+ * only (main.py:355); B > 1 is the batched form of the same call.  nprobe is ignored for
+ * FLAT (0 = index default for IVF).  1 <= k <= 256. */
+int sqe_index_search(sqe_index* idx, const float* q_host, int B, int k, int nprobe,
+                     float* cos_out_host, int64_t* id_out_host);
+int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, int nprobe,
+                            float* cos_out_dev, int64_t* id_out_dev);
+
+/* IVF only: k-means (spherical, Lloyd) on a sample, then (re)assignment of stored rows. */
+int sqe_index_train(sqe_index* idx, const float* x_host, int64_t n, int iters, uint64_t seed);
+int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int iters, uint64_t seed);
+
+/* Merge of per-shard results after the all-gather of a row-sharded index: parts are
+ * [P, B, k] (cos fp32, global ids int64, -1 padded); out is [B, k], best first, ties to
+ * the lowest id.  Device pointers, context stream. */
+int sqe_merge_topk_device(sqe_ctx* ctx, const float* cos_parts_dev, const int64_t* id_parts_dev,
+                          int P, int B, int k, float* cos_out_dev, int64_t* id_out_dev);
+
+/* ---- semantic cache scan: stands behind the loop of lfu_cache_get (main.py:73-87) -- */
+/* One-shot form: mat is [m, dim] raw (un-normalised) cached embeddings in list order
+ * (index 0 = newest), q is [dim] raw.  cosine = dot / (||a|| * ||b||) in fp32 with the
+ * zero-norm rule (main.py:59-64); returns the FIRST strict maximum starting from
+ * (-1.0, -1) exactly as main.py:74-87 does (NaN never wins). */
+int sqe_cosine_best(sqe_ctx* ctx, const float* mat_host, int m, int dim, const float* q_host,
+                    float* best_sim, int32_t* best_idx);
+/* All m cosines (the values cosine_similarity returns, main.py:59-64). */
+int sqe_cosine_all(sqe_ctx* ctx, const float* mat_host, int m, int dim, const float* q_host,
+                   float* sims_out_host);
+
+/* Resident form: the cache matrix lives in HBM; the host keeps the LFU bookkeeping
+ * (freq counters, JSON payloads) and tells the library which slot holds which list
+ * position.  `order_host[i]` = slot of list position i (position 0 = newest). */
+int sqe_cache_create(sqe_ctx* ctx, int capacity, int dim, sqe_cache** out);
+void sqe_cache_destroy(sqe_cache* c);
+int sqe_cache_set_slot(sqe_cache* c, int slot, const float* vec_host);
+int sqe_cache_best(sqe_cache* c, const int32_t* order_host, int m, const float* q_host,
+                   float* best_sim, int32_t* best_pos);
+
+/* ---- encoder: stands behind ollama_embed_text (main.py:134-145) ------------------ */
+typedef struct sqe_bert_cfg {
+    int32_t vocab_size;  /* 30522 */
+    int32_t hidden;      /* 1024 */
+    int32_t layers;      /* 24 */
+    int32_t heads;       /* 16 */
+    int32_t inter;       /* 4096 */
+    int32_t max_pos;     /* 512 */
+    int32_t type_vocab;  /* 2 */
+    float ln_eps;        /* 1e-12 */
+} sqe_bert_cfg;
+
+/* Tensors are fp32 host arrays named as in the HF BertModel state dict
+ * ("embeddings.word_embeddings.weight", "encoder.layer.0.attention.self.query.weight"...);
+ * they are converted to bf16 (matrices, embeddings) / fp32 (biases, LayerNorm) on load. */
+int sqe_encoder_create(sqe_ctx* ctx, const sqe_bert_cfg* cfg, sqe_encoder** out);
+void sqe_encoder_destroy(sqe_encoder* enc);
+int sqe_encoder_load_tensor(sqe_encoder* enc, const char* name, const float* data_host,
+                            const int64_t* shape, int ndim);
+int sqe_encoder_finalize(sqe_encoder* enc);
+/* Host-only BERT WordPiece (lower-case, accent strip, punctuation/CJK split, greedy
+ * longest match, [CLS]/[SEP], truncation to max_len).  vocab: one token per line. */
+int sqe_tokenizer_load(sqe_encoder* enc, const char* vocab_utf8, int64_t vocab_bytes);
+int sqe_tokenize(sqe_encoder* enc, const char* text_utf8, int max_len, int32_t* ids_out, int* len_out);
+/* ids [B,S] int32 row-major (anything past lens[b] is ignored), lens [B];
+ * out [B, hidden] fp32 = final-layer CLS row (no normalisation, as Ollama's
+ * /api/embeddings output feeds main.py:315-316 and :59-64 un-normalised). */
+int sqe_encode(sqe_encoder* enc, const int32_t* ids_host, const int32_t* lens_host, int B, int S,
+               float* out_host);
+int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S,
+                      float* out_dev);
+
+/* ---- stats ----------------------------------------------------------------------- */
+/* When profiling is on, every stage is bracketed by hipEvents on the context stream;
+ * sqe_stats reads the accumulated totals (it synchronises the stream). */
+typedef struct sqe_stats_t {
+    double scan_ms;        /* bf16/fp32 scan kernel (the dominant kernel of search) */
+    double prep_ms;        /* query normalise + cast */
+    double select_ms;      /* candidate merge + fp32 rescore + final top-k */
+    double add_ms;         /* normalise + cast of added rows */
+    double encode_ms;      /* encoder forward */
+    double cache_ms;       /* cache scan */
+    int64_t scan_calls;
+    int64_t search_calls;
+    int64_t scan_rows;     /* rows scanned by the last search */
+    int64_t scan_flops;    /* 2 * rows * dim * B of the last search */
+    int64_t scan_bytes;    /* algorithmic bytes of the last search */
+} sqe_stats_t;
+int sqe_set_profiling(sqe_ctx* ctx, int on);
+int sqe_stats(sqe_ctx* ctx, sqe_stats_t* out);
+int sqe_stats_reset(sqe_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQE_H */

@@ -1,0 +1,609 @@
+// api.hip -- the C ABI of include/sqe.h: context, flat vector index, search pipeline,
+// cache scan and stats.  No C++ types or exceptions cross this boundary.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+
+namespace sqe {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------- device buffer helper
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grows (never shrinks); contents are NOT preserved
+    int ensure(size_t need) {
+        if (need <= bytes) return SQE_OK;
+        release();
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(SQE_ERR_OOM, std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
+        }
+        bytes = need;
+        return SQE_OK;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------- profiling
+enum Stage { ST_SCAN = 0, ST_PREP, ST_SELECT, ST_ADD, ST_ENCODE, ST_CACHE, ST_COUNT };
+
+struct Profiler {
+    bool on = false;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[ST_COUNT] = {0};
+    int64_t calls[ST_COUNT] = {0};
+
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void drain(hipStream_t s) {
+        if (pending.empty()) return;
+        (void)hipStreamSynchronize(s);
+        for (auto& pd : pending) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, pd.a, pd.b) == hipSuccess) { ms[pd.stage] += t; calls[pd.stage]++; }
+            pool.push_back(pd.a);
+            pool.push_back(pd.b);
+        }
+        pending.clear();
+    }
+    ~Profiler() {
+        for (auto& pd : pending) { (void)hipEventDestroy(pd.a); (void)hipEventDestroy(pd.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+struct StageTimer {
+    Profiler& pf; hipStream_t s; int stage; hipEvent_t a = nullptr;
+    StageTimer(Profiler& p, hipStream_t st, int stg) : pf(p), s(st), stage(stg) {
+        if (pf.on) {
+            if (pf.pending.size() >= 2048) pf.drain(s);
+            a = pf.get();
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~StageTimer() {
+        if (pf.on && a) {
+            hipEvent_t b = pf.get();
+            (void)hipEventRecord(b, s);
+            pf.pending.push_back({stage, a, b});
+        }
+    }
+};
+
+}  // namespace sqe
+
+using namespace sqe;
+
+// ================================================================ objects
+struct sqe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::recursive_mutex mu;
+    int cu_count = 256;
+    int64_t hbm_bytes = 0;
+    std::string name;
+    Profiler prof;
+    int64_t last_scan_rows = 0, last_scan_flops = 0, last_scan_bytes = 0, search_calls = 0;
+    DevBuf stage_in;    // generic H2D staging
+    DevBuf stage_out;   // generic D2H staging
+    DevBuf cache_tmp;   // one-shot cosine scan: matrix + q + sims + best
+};
+
+struct sqe_index {
+    sqe_ctx* ctx = nullptr;
+    int dim = 0;
+    int kind = SQE_INDEX_FLAT;
+    int nlist = 0;
+    int64_t n = 0;
+    int64_t cap = 0;               // rows allocated (multiple of 256)
+    float* master = nullptr;       // [cap, dim] fp32 normalised
+    bf16_t* scan = nullptr;        // [cap, dim] bf16 normalised, zero past n
+    int scan_mode = SQE_SCAN_BF16_RESCORE;
+    int rescore_k = 0;             // 0 = automatic
+    int nprobe = 0;
+    DevBuf qn;                     // [B, dim] fp32 normalised queries
+    DevBuf qb;                     // [b_pad, dim] bf16 queries
+    DevBuf cand;                   // [n_chunks, b_pad, CAND_CAP] u64
+    DevBuf cand_cnt;               // [n_chunks, b_pad] int
+};
+
+struct sqe_cache {
+    sqe_ctx* ctx = nullptr;
+    int capacity = 0, dim = 0;
+    DevBuf mat;     // [capacity, dim] raw fp32
+    DevBuf work;    // q [dim] | sims [capacity] | best_sim | best_idx | order [capacity]
+};
+
+namespace {
+
+struct DeviceGuard {
+    explicit DeviceGuard(sqe_ctx* c) { (void)hipSetDevice(c->device); }
+};
+
+#define SQE_ENTER(ctxptr)                                              \
+    if (!(ctxptr)) return fail(SQE_ERR_INVALID, "null handle");        \
+    std::lock_guard<std::recursive_mutex> _lk((ctxptr)->mu);           \
+    DeviceGuard _dg(ctxptr)
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int index_grow(sqe_index* idx, int64_t need_rows) {
+    if (need_rows <= idx->cap) return SQE_OK;
+    sqe_ctx* c = idx->ctx;
+    int64_t new_cap = std::max<int64_t>(need_rows, idx->cap + idx->cap / 2);
+    new_cap = round_up(std::max<int64_t>(new_cap, 1024), SCAN_BM);
+    const size_t row_f = (size_t)idx->dim * 4, row_b = (size_t)idx->dim * 2;
+    float* nm = nullptr;
+    bf16_t* ns = nullptr;
+    hipError_t e = hipMalloc((void**)&nm, (size_t)new_cap * row_f);
+    if (e != hipSuccess) return fail(SQE_ERR_OOM, std::string("index master alloc: ") + hipGetErrorString(e));
+    e = hipMalloc((void**)&ns, (size_t)new_cap * row_b);
+    if (e != hipSuccess) { (void)hipFree(nm); return fail(SQE_ERR_OOM, std::string("index scan-copy alloc: ") + hipGetErrorString(e)); }
+    // rows past n of the scanned copy must read as zero (tile padding)
+    SQE_HIP(hipMemsetAsync(ns, 0, (size_t)new_cap * row_b, c->stream));
+    if (idx->n > 0) {
+        SQE_HIP(hipMemcpyAsync(nm, idx->master, (size_t)idx->n * row_f, hipMemcpyDeviceToDevice, c->stream));
+        SQE_HIP(hipMemcpyAsync(ns, idx->scan, (size_t)idx->n * row_b, hipMemcpyDeviceToDevice, c->stream));
+    }
+    SQE_HIP(hipStreamSynchronize(c->stream));
+    if (idx->master) (void)hipFree(idx->master);
+    if (idx->scan) (void)hipFree(idx->scan);
+    idx->master = nm;
+    idx->scan = ns;
+    idx->cap = new_cap;
+    return SQE_OK;
+}
+
+int auto_kp(const sqe_index* idx, int k) {
+    if (idx->rescore_k > 0) return std::min(MAX_KP, std::max(idx->rescore_k, k));
+    // bf16 scores of unit vectors carry ~1e-4 absolute error: keep a 3x margin, at least 32
+    return std::min(MAX_KP, std::max(32, 3 * k));
+}
+
+}  // namespace
+
+// ================================================================ library / context
+extern "C" {
+
+int sqe_version(void) { return SQE_VERSION; }
+const char* sqe_last_error(void) { return g_last_error.c_str(); }
+
+int sqe_create(const int* device_ids, int n_dev, sqe_ctx** out) {
+    if (!out) return fail(SQE_ERR_INVALID, "sqe_create: out is null");
+    *out = nullptr;
+    if (n_dev != 1 || !device_ids)
+        return fail(SQE_ERR_INVALID, "sqe_create: one context drives one device (one process per GPU)");
+    int count = 0;
+    SQE_HIP(hipGetDeviceCount(&count));
+    if (device_ids[0] < 0 || device_ids[0] >= count)
+        return fail(SQE_ERR_INVALID, "sqe_create: no such HIP device");
+    std::unique_ptr<sqe_ctx> c(new (std::nothrow) sqe_ctx);
+    if (!c) return fail(SQE_ERR_OOM, "sqe_create: host allocation failed");
+    c->device = device_ids[0];
+    SQE_HIP(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    SQE_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->cu_count = prop.multiProcessorCount;
+    c->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    c->name = prop.name;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(SQE_ERR_UNSUPPORTED, std::string("libsqe is built for gfx950 only, device is ") + prop.gcnArchName);
+    SQE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c.release();
+    return SQE_OK;
+}
+
+void sqe_destroy(sqe_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int sqe_synchronize(sqe_ctx* ctx) {
+    SQE_ENTER(ctx);
+    SQE_HIP(hipStreamSynchronize(ctx->stream));
+    return SQE_OK;
+}
+
+void* sqe_stream(sqe_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sqe_device_info(sqe_ctx* ctx, char* name, int name_cap, int* cu_count, int64_t* hbm_bytes) {
+    SQE_ENTER(ctx);
+    if (name && name_cap > 0) {
+        strncpy(name, ctx->name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (cu_count) *cu_count = ctx->cu_count;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return SQE_OK;
+}
+
+// ================================================================ index
+int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out) {
+    SQE_ENTER(ctx);
+    if (!out) return fail(SQE_ERR_INVALID, "sqe_index_create: out is null");
+    *out = nullptr;
+    if (dim <= 0 || dim % SCAN_BK != 0 || dim > 8192)
+        return fail(SQE_ERR_INVALID, "sqe_index_create: dim must be a positive multiple of 64 (<= 8192)");
+    if (kind != SQE_INDEX_FLAT)
+        return fail(SQE_ERR_UNSUPPORTED, "sqe_index_create: only SQE_INDEX_FLAT is implemented in this build");
+    sqe_index* idx = new (std::nothrow) sqe_index;
+    if (!idx) return fail(SQE_ERR_OOM, "sqe_index_create: host allocation failed");
+    idx->ctx = ctx;
+    idx->dim = dim;
+    idx->kind = kind;
+    idx->nlist = nlist;
+    *out = idx;
+    return SQE_OK;
+}
+
+void sqe_index_destroy(sqe_index* idx) {
+    if (!idx) return;
+    {
+        std::lock_guard<std::recursive_mutex> lk(idx->ctx->mu);
+        (void)hipSetDevice(idx->ctx->device);
+        (void)hipStreamSynchronize(idx->ctx->stream);
+        if (idx->master) (void)hipFree(idx->master);
+        if (idx->scan) (void)hipFree(idx->scan);
+        idx->qn.release(); idx->qb.release(); idx->cand.release(); idx->cand_cnt.release();
+    }
+    delete idx;
+}
+
+int sqe_index_reserve(sqe_index* idx, int64_t rows) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (rows < 0) return fail(SQE_ERR_INVALID, "sqe_index_reserve: rows < 0");
+    return index_grow(idx, rows);
+}
+
+int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (n < 0 || (n > 0 && !x_dev)) return fail(SQE_ERR_INVALID, "sqe_index_add: bad arguments");
+    if (n == 0) return SQE_OK;
+    if (idx->n + n > 0xFFFFFFF0LL) return fail(SQE_ERR_INVALID, "sqe_index_add: more than 2^32 rows per shard");
+    SQE_TRY(index_grow(idx, idx->n + n));
+    {
+        StageTimer t(idx->ctx->prof, idx->ctx->stream, ST_ADD);
+        SQE_TRY(launch_normalize_rows(x_dev, n, idx->dim, idx->master + (size_t)idx->n * idx->dim,
+                                      idx->scan + (size_t)idx->n * idx->dim, idx->ctx->stream));
+    }
+    idx->n += n;
+    return SQE_OK;
+}
+
+int sqe_index_add(sqe_index* idx, const float* x_host, int64_t n) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (n < 0 || (n > 0 && !x_host)) return fail(SQE_ERR_INVALID, "sqe_index_add: bad arguments");
+    if (n == 0) return SQE_OK;
+    sqe_ctx* c = idx->ctx;
+    SQE_TRY(index_grow(idx, idx->n + n));
+    const int64_t rows_per_step = std::max<int64_t>(1, (64ll << 20) / ((int64_t)idx->dim * 4));
+    SQE_TRY(c->stage_in.ensure((size_t)std::min(rows_per_step, n) * idx->dim * 4));
+    for (int64_t off = 0; off < n; off += rows_per_step) {
+        const int64_t m = std::min(rows_per_step, n - off);
+        SQE_HIP(hipMemcpyAsync(c->stage_in.p, x_host + (size_t)off * idx->dim, (size_t)m * idx->dim * 4,
+                               hipMemcpyHostToDevice, c->stream));
+        SQE_TRY(sqe_index_add_device(idx, c->stage_in.as<float>(), m));
+    }
+    SQE_HIP(hipStreamSynchronize(c->stream));   // x_host is not retained past return
+    return SQE_OK;
+}
+
+int sqe_index_update(sqe_index* idx, const int64_t* rows_host, const float* x_host, int64_t n) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (n < 0 || (n > 0 && (!rows_host || !x_host))) return fail(SQE_ERR_INVALID, "sqe_index_update: bad arguments");
+    if (n == 0) return SQE_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (rows_host[i] < 0 || rows_host[i] >= idx->n) return fail(SQE_ERR_INVALID, "sqe_index_update: row out of range");
+    sqe_ctx* c = idx->ctx;
+    const size_t xb = (size_t)n * idx->dim * 4, rb = (size_t)n * 8;
+    SQE_TRY(c->stage_in.ensure(xb + rb));
+    SQE_HIP(hipMemcpyAsync(c->stage_in.p, x_host, xb, hipMemcpyHostToDevice, c->stream));
+    SQE_HIP(hipMemcpyAsync((char*)c->stage_in.p + xb, rows_host, rb, hipMemcpyHostToDevice, c->stream));
+    SQE_TRY(launch_normalize_rows_scatter(c->stage_in.as<float>(), (const int64_t*)((char*)c->stage_in.p + xb), n,
+                                          idx->dim, idx->master, idx->scan, c->stream));
+    SQE_HIP(hipStreamSynchronize(c->stream));
+    return SQE_OK;
+}
+
+int sqe_index_count(const sqe_index* idx, int64_t* out) {
+    if (!idx || !out) return fail(SQE_ERR_INVALID, "sqe_index_count: null argument");
+    std::lock_guard<std::recursive_mutex> lk(idx->ctx->mu);
+    *out = idx->n;
+    return SQE_OK;
+}
+
+int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, float* out_host) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (n < 0 || (n > 0 && (!rows_host || !out_host))) return fail(SQE_ERR_INVALID, "sqe_index_get_rows: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        if (rows_host[i] < 0 || rows_host[i] >= idx->n) return fail(SQE_ERR_INVALID, "sqe_index_get_rows: row out of range");
+        SQE_HIP(hipMemcpyAsync(out_host + (size_t)i * idx->dim, idx->master + (size_t)rows_host[i] * idx->dim,
+                               (size_t)idx->dim * 4, hipMemcpyDeviceToHost, idx->ctx->stream));
+    }
+    SQE_HIP(hipStreamSynchronize(idx->ctx->stream));
+    return SQE_OK;
+}
+
+int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
+    if (!idx || !key) return fail(SQE_ERR_INVALID, "sqe_index_set_option: null argument");
+    SQE_ENTER(idx->ctx);
+    const std::string k(key);
+    if (k == "scan_mode") {
+        if ((int)value != SQE_SCAN_BF16_RESCORE)
+            return fail(SQE_ERR_UNSUPPORTED, "scan_mode: only SQE_SCAN_BF16_RESCORE is implemented in this build");
+        idx->scan_mode = (int)value;
+    } else if (k == "rescore_k") {
+        if (value < 0 || value > MAX_KP) return fail(SQE_ERR_INVALID, "rescore_k must be in [0, 256]");
+        idx->rescore_k = (int)value;
+    } else if (k == "nprobe") {
+        idx->nprobe = (int)value;
+    } else {
+        return fail(SQE_ERR_INVALID, "unknown option: " + k);
+    }
+    return SQE_OK;
+}
+
+int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, int nprobe,
+                            float* cos_out_dev, int64_t* id_out_dev) {
+    (void)nprobe;
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (B < 0 || k < 1 || k > MAX_KP) return fail(SQE_ERR_INVALID, "sqe_index_search: need B >= 0 and 1 <= k <= 256");
+    if (B == 0) return SQE_OK;
+    if (!q_dev || !cos_out_dev || !id_out_dev) return fail(SQE_ERR_INVALID, "sqe_index_search: null buffer");
+    sqe_ctx* c = idx->ctx;
+    const int K = idx->dim;
+    const int kp = auto_kp(idx, k);
+    const ScanPlan plan = make_scan_plan(idx->n, B, kp, c->cu_count);
+
+    SQE_TRY(idx->qn.ensure((size_t)B * K * 4));
+    SQE_TRY(idx->qb.ensure((size_t)plan.b_pad * K * 2));
+    SQE_TRY(idx->cand.ensure((size_t)plan.n_chunks * plan.b_pad * CAND_CAP * 8));
+    SQE_TRY(idx->cand_cnt.ensure((size_t)plan.n_chunks * plan.b_pad * 4));
+    {
+        StageTimer t(c->prof, c->stream, ST_PREP);
+        if (plan.b_pad > B)
+            SQE_HIP(hipMemsetAsync(idx->qb.as<char>() + (size_t)B * K * 2, 0, (size_t)(plan.b_pad - B) * K * 2, c->stream));
+        SQE_TRY(launch_normalize_rows(q_dev, B, K, idx->qn.as<float>(), idx->qb.as<bf16_t>(), c->stream));
+    }
+    if (idx->n > 0) {
+        StageTimer t(c->prof, c->stream, ST_SCAN);
+        ScanArgs a;
+        a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
+        a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>();
+        SQE_TRY(launch_scan_bf16(plan, a, c->stream));
+    } else {
+        SQE_HIP(hipMemsetAsync(idx->cand_cnt.p, 0, (size_t)plan.n_chunks * plan.b_pad * 4, c->stream));
+    }
+    {
+        StageTimer t(c->prof, c->stream, ST_SELECT);
+        SelectArgs s;
+        s.cand = idx->cand.as<uint64_t>(); s.cand_cnt = idx->cand_cnt.as<int>();
+        s.n_chunks = plan.n_chunks; s.b_pad = plan.b_pad; s.kp = kp;
+        s.master = idx->master; s.qn = idx->qn.as<float>(); s.K = K; s.B = B; s.k = k;
+        s.cos_out = cos_out_dev; s.id_out = id_out_dev; s.id_base = 0;
+        SQE_TRY(launch_select_rescore(s, c->stream));
+    }
+    c->search_calls++;
+    c->last_scan_rows = idx->n;
+    c->last_scan_flops = 2 * idx->n * (int64_t)K * B;
+    c->last_scan_bytes = idx->n * (int64_t)K * 2 + (int64_t)B * K * 4 + (int64_t)B * k * 12;
+    return SQE_OK;
+}
+
+int sqe_index_search(sqe_index* idx, const float* q_host, int B, int k, int nprobe,
+                     float* cos_out_host, int64_t* id_out_host) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (B < 0 || k < 1 || k > MAX_KP) return fail(SQE_ERR_INVALID, "sqe_index_search: need B >= 0 and 1 <= k <= 256");
+    if (B == 0) return SQE_OK;
+    if (!q_host || !cos_out_host || !id_out_host) return fail(SQE_ERR_INVALID, "sqe_index_search: null buffer");
+    sqe_ctx* c = idx->ctx;
+    const size_t qbytes = (size_t)B * idx->dim * 4, cb = (size_t)B * k * 4, ib = (size_t)B * k * 8;
+    SQE_TRY(c->stage_in.ensure(qbytes));
+    SQE_TRY(c->stage_out.ensure(round_up((int64_t)cb, 16) + ib));
+    float* cos_dev = c->stage_out.as<float>();
+    int64_t* id_dev = reinterpret_cast<int64_t*>(c->stage_out.as<char>() + round_up((int64_t)cb, 16));
+    SQE_HIP(hipMemcpyAsync(c->stage_in.p, q_host, qbytes, hipMemcpyHostToDevice, c->stream));
+    SQE_TRY(sqe_index_search_device(idx, c->stage_in.as<float>(), B, k, nprobe, cos_dev, id_dev));
+    SQE_HIP(hipMemcpyAsync(cos_out_host, cos_dev, cb, hipMemcpyDeviceToHost, c->stream));
+    SQE_HIP(hipMemcpyAsync(id_out_host, id_dev, ib, hipMemcpyDeviceToHost, c->stream));
+    SQE_HIP(hipStreamSynchronize(c->stream));
+    return SQE_OK;
+}
+
+int sqe_index_train(sqe_index* idx, const float*, int64_t, int, uint64_t) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    return fail(SQE_ERR_UNSUPPORTED, "sqe_index_train: IVF is not implemented in this build");
+}
+int sqe_index_train_device(sqe_index* idx, const float*, int64_t, int, uint64_t) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    return fail(SQE_ERR_UNSUPPORTED, "sqe_index_train: IVF is not implemented in this build");
+}
+
+int sqe_merge_topk_device(sqe_ctx* ctx, const float* cos_parts_dev, const int64_t* id_parts_dev,
+                          int P, int B, int k, float* cos_out_dev, int64_t* id_out_dev) {
+    SQE_ENTER(ctx);
+    if (!cos_parts_dev || !id_parts_dev || !cos_out_dev || !id_out_dev)
+        return fail(SQE_ERR_INVALID, "sqe_merge_topk: null buffer");
+    return launch_merge_topk(cos_parts_dev, id_parts_dev, P, B, k, cos_out_dev, id_out_dev, ctx->stream);
+}
+
+// ================================================================ cache scan
+static int cosine_scan_host(sqe_ctx* ctx, const float* mat_host, int m, int dim, const float* q_host,
+                            float* sims_out_host, float* best_sim, int32_t* best_idx) {
+    if (m < 0 || dim <= 0 || dim % 4 != 0) return fail(SQE_ERR_INVALID, "cosine scan: bad m/dim");
+    if (!q_host || (m > 0 && !mat_host)) return fail(SQE_ERR_INVALID, "cosine scan: null buffer");
+    const size_t mb = (size_t)m * dim * 4, qb = (size_t)dim * 4, sb = round_up((int64_t)m * 4 + 4, 16);
+    SQE_TRY(ctx->cache_tmp.ensure(mb + qb + sb + 16));
+    char* base = ctx->cache_tmp.as<char>();
+    float* d_mat = (float*)base;
+    float* d_q = (float*)(base + mb);
+    float* d_sims = (float*)(base + mb + qb);
+    float* d_best = (float*)(base + mb + qb + sb);
+    int32_t* d_idx = (int32_t*)(base + mb + qb + sb + 4);
+    if (m > 0) SQE_HIP(hipMemcpyAsync(d_mat, mat_host, mb, hipMemcpyHostToDevice, ctx->stream));
+    SQE_HIP(hipMemcpyAsync(d_q, q_host, qb, hipMemcpyHostToDevice, ctx->stream));
+    {
+        StageTimer t(ctx->prof, ctx->stream, ST_CACHE);
+        SQE_TRY(launch_cosine_scan(d_mat, nullptr, m, dim, d_q, d_sims, d_best, d_idx, ctx->stream));
+    }
+    if (sims_out_host && m > 0)
+        SQE_HIP(hipMemcpyAsync(sims_out_host, d_sims, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (best_sim) SQE_HIP(hipMemcpyAsync(best_sim, d_best, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (best_idx) SQE_HIP(hipMemcpyAsync(best_idx, d_idx, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQE_HIP(hipStreamSynchronize(ctx->stream));
+    return SQE_OK;
+}
+
+int sqe_cosine_best(sqe_ctx* ctx, const float* mat_host, int m, int dim, const float* q_host,
+                    float* best_sim, int32_t* best_idx) {
+    SQE_ENTER(ctx);
+    if (!best_sim || !best_idx) return fail(SQE_ERR_INVALID, "sqe_cosine_best: null output");
+    return cosine_scan_host(ctx, mat_host, m, dim, q_host, nullptr, best_sim, best_idx);
+}
+
+int sqe_cosine_all(sqe_ctx* ctx, const float* mat_host, int m, int dim, const float* q_host,
+                   float* sims_out_host) {
+    SQE_ENTER(ctx);
+    if (m > 0 && !sims_out_host) return fail(SQE_ERR_INVALID, "sqe_cosine_all: null output");
+    float bs; int32_t bi;
+    return cosine_scan_host(ctx, mat_host, m, dim, q_host, sims_out_host, &bs, &bi);
+}
+
+int sqe_cache_create(sqe_ctx* ctx, int capacity, int dim, sqe_cache** out) {
+    SQE_ENTER(ctx);
+    if (!out) return fail(SQE_ERR_INVALID, "sqe_cache_create: out is null");
+    *out = nullptr;
+    if (capacity <= 0 || dim <= 0 || dim % 4 != 0) return fail(SQE_ERR_INVALID, "sqe_cache_create: bad capacity/dim");
+    std::unique_ptr<sqe_cache> c(new (std::nothrow) sqe_cache);
+    if (!c) return fail(SQE_ERR_OOM, "sqe_cache_create: host allocation failed");
+    c->ctx = ctx; c->capacity = capacity; c->dim = dim;
+    SQE_TRY(c->mat.ensure((size_t)capacity * dim * 4));
+    SQE_TRY(c->work.ensure((size_t)dim * 4 + (size_t)capacity * 8 + 64));
+    SQE_HIP(hipMemsetAsync(c->mat.p, 0, (size_t)capacity * dim * 4, ctx->stream));
+    *out = c.release();
+    return SQE_OK;
+}
+
+void sqe_cache_destroy(sqe_cache* c) {
+    if (!c) return;
+    {
+        std::lock_guard<std::recursive_mutex> lk(c->ctx->mu);
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+        c->mat.release(); c->work.release();
+    }
+    delete c;
+}
+
+int sqe_cache_set_slot(sqe_cache* c, int slot, const float* vec_host) {
+    if (!c) return fail(SQE_ERR_INVALID, "null cache");
+    SQE_ENTER(c->ctx);
+    if (slot < 0 || slot >= c->capacity || !vec_host) return fail(SQE_ERR_INVALID, "sqe_cache_set_slot: bad slot");
+    SQE_HIP(hipMemcpyAsync(c->mat.as<float>() + (size_t)slot * c->dim, vec_host, (size_t)c->dim * 4,
+                           hipMemcpyHostToDevice, c->ctx->stream));
+    SQE_HIP(hipStreamSynchronize(c->ctx->stream));
+    return SQE_OK;
+}
+
+int sqe_cache_best(sqe_cache* c, const int32_t* order_host, int m, const float* q_host,
+                   float* best_sim, int32_t* best_pos) {
+    if (!c) return fail(SQE_ERR_INVALID, "null cache");
+    SQE_ENTER(c->ctx);
+    if (m < 0 || m > c->capacity || !q_host || !best_sim || !best_pos || (m > 0 && !order_host))
+        return fail(SQE_ERR_INVALID, "sqe_cache_best: bad arguments");
+    for (int i = 0; i < m; ++i)
+        if (order_host[i] < 0 || order_host[i] >= c->capacity) return fail(SQE_ERR_INVALID, "sqe_cache_best: slot out of range");
+    sqe_ctx* ctx = c->ctx;
+    char* base = c->work.as<char>();
+    float* d_q = (float*)base;
+    float* d_sims = (float*)(base + (size_t)c->dim * 4);
+    int32_t* d_order = (int32_t*)(base + (size_t)c->dim * 4 + (size_t)c->capacity * 4);
+    float* d_best = (float*)(base + (size_t)c->dim * 4 + (size_t)c->capacity * 8);
+    int32_t* d_idx = (int32_t*)(d_best + 1);
+    SQE_HIP(hipMemcpyAsync(d_q, q_host, (size_t)c->dim * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (m > 0) SQE_HIP(hipMemcpyAsync(d_order, order_host, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        StageTimer t(ctx->prof, ctx->stream, ST_CACHE);
+        SQE_TRY(launch_cosine_scan(c->mat.as<float>(), d_order, m, c->dim, d_q, d_sims, d_best, d_idx, ctx->stream));
+    }
+    SQE_HIP(hipMemcpyAsync(best_sim, d_best, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQE_HIP(hipMemcpyAsync(best_pos, d_idx, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQE_HIP(hipStreamSynchronize(ctx->stream));
+    return SQE_OK;
+}
+
+// ================================================================ stats
+int sqe_set_profiling(sqe_ctx* ctx, int on) {
+    SQE_ENTER(ctx);
+    ctx->prof.drain(ctx->stream);
+    ctx->prof.on = on != 0;
+    return SQE_OK;
+}
+
+int sqe_stats(sqe_ctx* ctx, sqe_stats_t* out) {
+    SQE_ENTER(ctx);
+    if (!out) return fail(SQE_ERR_INVALID, "sqe_stats: out is null");
+    ctx->prof.drain(ctx->stream);
+    memset(out, 0, sizeof(*out));
+    out->scan_ms = ctx->prof.ms[ST_SCAN];
+    out->prep_ms = ctx->prof.ms[ST_PREP];
+    out->select_ms = ctx->prof.ms[ST_SELECT];
+    out->add_ms = ctx->prof.ms[ST_ADD];
+    out->encode_ms = ctx->prof.ms[ST_ENCODE];
+    out->cache_ms = ctx->prof.ms[ST_CACHE];
+    out->scan_calls = ctx->prof.calls[ST_SCAN];
+    out->search_calls = ctx->search_calls;
+    out->scan_rows = ctx->last_scan_rows;
+    out->scan_flops = ctx->last_scan_flops;
+    out->scan_bytes = ctx->last_scan_bytes;
+    return SQE_OK;
+}
+
+int sqe_stats_reset(sqe_ctx* ctx) {
+    SQE_ENTER(ctx);
+    ctx->prof.drain(ctx->stream);
+    for (int i = 0; i < ST_COUNT; ++i) { ctx->prof.ms[i] = 0; ctx->prof.calls[i] = 0; }
+    ctx->search_calls = 0;
+    return SQE_OK;
+}
+
+}  // extern "C"

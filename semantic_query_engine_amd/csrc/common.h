@@ -1,0 +1,75 @@
+// common.h -- shared device/host helpers for libsqe (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "sqe.h"
+
+namespace sqe {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define SQE_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            return ::sqe::fail(_e == hipErrorOutOfMemory ? SQE_ERR_OOM : SQE_ERR_HIP,   \
+                               std::string(#expr) + ": " + hipGetErrorString(_e));      \
+        }                                                                               \
+    } while (0)
+
+#define SQE_TRY(expr)              \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != SQE_OK) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------- types
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- device helpers
+// fp32 -> bf16 bits, round to nearest even; NaN stays NaN (quiet).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// Order-preserving map float -> uint32 (larger float <=> larger uint); NaNs are
+// never fed to it (they fail the `s >= thr` filter first).
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+// Candidate key: (orderable(score) << 32) | (0xFFFFFFFF - row).  Larger key = better:
+// higher score first, then LOWER row id.  Keys are unique because rows are.
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t row) {
+    return ((uint64_t)f32_orderable(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+__device__ __forceinline__ uint32_t key_row(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)key; }
+__device__ __forceinline__ float key_score(uint64_t key) { return f32_from_orderable((uint32_t)(key >> 32)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace sqe

@@ -1,0 +1,69 @@
+// kernels.h -- host-callable launchers of the HIP kernels (gfx950).
+#pragma once
+
+#include "common.h"
+
+namespace sqe {
+
+// ------------------------------------------------------------------ normalise (S1)
+// out = x / (||x||_2 + 1e-9) per row, fp32 (main.py:315-316, 353-354); optionally also a
+// bf16 copy (the scanned copy).  Either output may be null.  dim % 4 == 0.
+int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
+                          hipStream_t stream);
+// Same, rows scattered to out row ids `rows[i]` (sqe_index_update).
+int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
+                                  float* out_f32, bf16_t* out_bf16, hipStream_t stream);
+
+// ------------------------------------------------------------------ flat scan (S2)
+constexpr int SCAN_BM = 256;        // DB rows per tile
+constexpr int SCAN_BK = 64;         // K elements per pipeline stage
+constexpr int CAND_CAP = 512;       // candidate slots per (chunk, query)
+constexpr int MAX_KP = 256;         // max candidates kept per (chunk, query)
+
+struct ScanPlan {
+    int bn;               // queries per workgroup tile (256 / 64 / 16)
+    int qblocks;          // ceil(B / bn)
+    int b_pad;            // qblocks * bn
+    int n_tiles;          // ceil(n_rows / SCAN_BM)
+    int n_chunks;         // DB chunks (persistent workgroups per query block)
+    int tiles_per_chunk;  // ceil(n_tiles / n_chunks)
+    int kp;               // candidates kept per (chunk, query)
+};
+ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count);
+
+struct ScanArgs {
+    const bf16_t* db;     // [round_up(n_rows, 256), K] bf16, zero rows past n_rows
+    const bf16_t* q;      // [b_pad, K] bf16, zero rows past B
+    int64_t n_rows;
+    int K;
+    int B;
+    uint64_t* cand;       // [n_chunks, b_pad, CAND_CAP] candidate keys
+    int* cand_cnt;        // [n_chunks, b_pad]
+};
+int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
+
+// ------------------------------------------------------------------ select + rescore (S3+S4)
+struct SelectArgs {
+    const uint64_t* cand;
+    const int* cand_cnt;
+    int n_chunks, b_pad, kp;
+    const float* master;   // [n_rows, K] fp32 normalised rows
+    const float* qn;       // [B, K] fp32 normalised queries
+    int K, B, k;
+    float* cos_out;        // [B, k]
+    int64_t* id_out;       // [B, k]
+    int64_t id_base;       // added to local row ids
+};
+int launch_select_rescore(const SelectArgs& args, hipStream_t stream);
+
+// merge of [P,B,k] partial results (multi-GPU all-gather output)
+int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int P, int B, int k,
+                      float* cos_out, int64_t* id_out, hipStream_t stream);
+
+// ------------------------------------------------------------------ cache scan (S8)
+// sims[i] = cosine(mat[slot(i)], q) with the zero-norm rule; slot(i) = order ? order[i] : i.
+// best = first strict max over i from (-1.0, -1).
+int launch_cosine_scan(const float* mat, const int32_t* order, int m, int dim, const float* q,
+                       float* sims, float* best_sim, int32_t* best_idx, hipStream_t stream);
+
+}  // namespace sqe

@@ -1,0 +1,68 @@
+// normalize.hip -- S1: row L2-normalisation x / (||x|| + 1e-9) in fp32, with an optional
+// bf16 copy.  Restates main.py:315-316 (index side) and main.py:353-354 (query side).
+//
+// Roofline: pure HBM stream.  Algorithmic bytes per row = dim * (4 read + 4 fp32 write +
+// 2 bf16 write).  One wave per row, float4 per lane per step (1 KiB per wave-instruction).
+#include "kernels.h"
+
+namespace sqe {
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x,
+                                                             const int64_t* __restrict__ rows,
+                                                             int64_t n, int dim,
+                                                             float* __restrict__ out_f32,
+                                                             bf16_t* __restrict__ out_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float4* src = reinterpret_cast<const float4*>(x + row * dim);
+    const int nvec = dim >> 2;
+    float ss = 0.f;
+    for (int i = lane; i < nvec; i += 64) {
+        float4 v = src[i];
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    // np.linalg.norm -> sqrt(sum of squares); then e / (norm + 1e-9) as a true division
+    const float den = sqrtf(ss) + 1e-9f;
+    const int64_t orow = SCATTER ? rows[row] : row;
+    float4* dst = out_f32 ? reinterpret_cast<float4*>(out_f32 + orow * dim) : nullptr;
+    uint2* dstb = out_bf16 ? reinterpret_cast<uint2*>(out_bf16 + orow * dim) : nullptr;
+    for (int i = lane; i < nvec; i += 64) {
+        float4 v = src[i];   // second read is an L1/L2 hit (row = 4 KiB at dim 1024)
+        v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+        if (dst) dst[i] = v;
+        if (dstb) {
+            uint2 p;
+            p.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            p.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            dstb[i] = p;
+        }
+    }
+}
+
+int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
+                          hipStream_t stream) {
+    if (n <= 0) return SQE_OK;
+    if (dim % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: dim must be a multiple of 4");
+    const int64_t blocks = (n + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(SQE_ERR_INVALID, "normalize: too many rows for one launch");
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       x, (const int64_t*)nullptr, n, dim, out_f32, out_bf16);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
+                                  float* out_f32, bf16_t* out_bf16, hipStream_t stream) {
+    if (n <= 0) return SQE_OK;
+    if (dim % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: dim must be a multiple of 4");
+    const int64_t blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(normalize_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       x, rows, n, dim, out_f32, out_bf16);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+}  // namespace sqe

@@ -1,0 +1,202 @@
+// select.hip -- S3 + S4: per query, merge the per-chunk candidate lists of the scan, keep
+// the best kp keys, re-score them in fp32 against the fp32 master rows, and emit the final
+// top-k ordered by (fp32 cosine desc, row id asc).  Also the [P,B,k] merge used after the
+// multi-GPU all-gather.
+//
+// Tiny kernels (B workgroups, a few KB each): latency-bound, not roofline-relevant.  The
+// rescore reads kp * dim * 4 bytes of the master per query (128 KiB at kp=32, dim=1024).
+#include "kernels.h"
+
+namespace sqe {
+
+namespace {
+
+constexpr int SEL_THREADS = 256;
+
+struct SelectKernelArgs {
+    const uint64_t* cand;
+    const int* cand_cnt;
+    int n_chunks, b_pad, kp;
+    const float* master;
+    const float* qn;
+    int K, B, k;
+    float* cos_out;
+    int64_t* id_out;
+    int64_t id_base;
+};
+
+// MSB-first byte-wise radix select of the `kth` largest key among the valid candidates of
+// query q.  Returns 0 when there are fewer than kth candidates (everything qualifies).
+__device__ uint64_t block_select_kth(const SelectKernelArgs& p, int q, int kth, int* hist, int* scratch) {
+    const int tid = threadIdx.x;
+    const int total_slots = p.n_chunks * p.kp;
+    uint64_t prefix = 0;      // determined high bytes
+    int remaining = kth;
+    for (int byte = 7; byte >= 0; --byte) {
+        hist[tid] = 0;        // SEL_THREADS == 256 bins
+        __syncthreads();
+        const int shift = byte * 8;
+        for (int e = tid; e < total_slots; e += SEL_THREADS) {
+            const int chunk = e / p.kp, slot = e - chunk * p.kp;
+            if (slot < p.cand_cnt[(size_t)chunk * p.b_pad + q]) {
+                const uint64_t key = p.cand[((size_t)chunk * p.b_pad + q) * CAND_CAP + slot];
+                const bool match = (byte == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, bin = 255;
+            for (; bin >= 0; --bin) {
+                if (cum + hist[bin] >= remaining) break;
+                cum += hist[bin];
+            }
+            scratch[0] = bin;          // -1: fewer than `remaining` keys in total
+            scratch[1] = remaining - cum;
+        }
+        __syncthreads();
+        const int bin = scratch[0];
+        if (bin < 0) return 0ull;
+        prefix |= ((uint64_t)bin << shift);
+        remaining = scratch[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKernelArgs p) {
+    __shared__ int hist[256];
+    __shared__ int scratch[4];
+    __shared__ uint32_t sel_row[MAX_KP];
+    __shared__ float sel_score[MAX_KP];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const uint64_t T = block_select_kth(p, q, p.kp, hist, scratch);
+
+    if (tid == 0) scratch[2] = 0;
+    __syncthreads();
+    const int total_slots = p.n_chunks * p.kp;
+    for (int e = tid; e < total_slots; e += SEL_THREADS) {
+        const int chunk = e / p.kp, slot = e - chunk * p.kp;
+        if (slot < p.cand_cnt[(size_t)chunk * p.b_pad + q]) {
+            const uint64_t key = p.cand[((size_t)chunk * p.b_pad + q) * CAND_CAP + slot];
+            if (key >= T) {
+                const int pos = atomicAdd(&scratch[2], 1);
+                if (pos < MAX_KP) sel_row[pos] = key_row(key);
+            }
+        }
+    }
+    __syncthreads();
+    const int m = min(scratch[2], p.kp);
+
+    // fp32 re-score: one wave per candidate, float4 per lane per step
+    const float4* qv = reinterpret_cast<const float4*>(p.qn + (size_t)q * p.K);
+    const int nvec = p.K >> 2;
+    for (int i = wave; i < m; i += SEL_THREADS / 64) {
+        const float4* rv = reinterpret_cast<const float4*>(p.master + (size_t)sel_row[i] * p.K);
+        float s = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            const float4 a = rv[v], b = qv[v];
+            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) sel_score[i] = s + 0.0f;
+    }
+    __syncthreads();
+
+    // final order: (score desc, row asc); NaN scores rank last
+    float* cos_out = p.cos_out + (size_t)q * p.k;
+    int64_t* id_out = p.id_out + (size_t)q * p.k;
+    for (int i = tid; i < m; i += SEL_THREADS) {
+        const float si = sel_score[i];
+        const uint32_t ri = sel_row[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const float sj = sel_score[j];
+            const uint32_t rj = sel_row[j];
+            const bool better = (si != si) ? (sj == sj || rj < ri)
+                                           : (sj > si || (sj == si && rj < ri));
+            rank += (j != i && better) ? 1 : 0;
+        }
+        if (rank < p.k) {
+            cos_out[rank] = si;
+            id_out[rank] = (int64_t)ri + p.id_base;
+        }
+    }
+    for (int i = m + tid; i < p.k; i += SEL_THREADS) {
+        cos_out[i] = -INFINITY;
+        id_out[i] = -1;
+    }
+}
+
+// ---- merge of P partial top-k lists per query (after the all-gather of a sharded index)
+__global__ __launch_bounds__(64) void merge_topk_kernel(const float* __restrict__ cos_parts,
+                                                        const int64_t* __restrict__ id_parts,
+                                                        int P, int B, int k,
+                                                        float* __restrict__ cos_out,
+                                                        int64_t* __restrict__ id_out) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int total = P * k;
+    // rank by counting: entry e = (part, j) beats f when cos higher, or equal cos and lower id
+    for (int e = lane; e < total; e += 64) {
+        const int part = e / k, j = e - part * k;
+        const float se = cos_parts[((size_t)part * B + q) * k + j];
+        const int64_t ie = id_parts[((size_t)part * B + q) * k + j];
+        if (ie < 0) continue;
+        int rank = 0;
+        for (int f = 0; f < total; ++f) {
+            const int pf = f / k, jf = f - pf * k;
+            const float sf = cos_parts[((size_t)pf * B + q) * k + jf];
+            const int64_t idf = id_parts[((size_t)pf * B + q) * k + jf];
+            if (f == e || idf < 0) continue;
+            const bool better = (se != se) ? (sf == sf || idf < ie) : (sf > se || (sf == se && idf < ie));
+            rank += better ? 1 : 0;
+        }
+        if (rank < k) {
+            cos_out[(size_t)q * k + rank] = se;
+            id_out[(size_t)q * k + rank] = ie;
+        }
+    }
+    // pad: number of valid entries
+    int valid = 0;
+    for (int e = lane; e < total; e += 64) {
+        const int part = e / k, j = e - part * k;
+        valid += id_parts[((size_t)part * B + q) * k + j] >= 0 ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) valid += __shfl_xor(valid, off, 64);
+    for (int i = valid + lane; i < k; i += 64) {
+        cos_out[(size_t)q * k + i] = -INFINITY;
+        id_out[(size_t)q * k + i] = -1;
+    }
+}
+
+}  // namespace
+
+int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return SQE_OK;
+    if (a.k < 1 || a.k > MAX_KP || a.kp < a.k || a.kp > MAX_KP)
+        return fail(SQE_ERR_INVALID, "select: need 1 <= k <= kp <= 256");
+    SelectKernelArgs k;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.n_chunks = a.n_chunks; k.b_pad = a.b_pad; k.kp = a.kp;
+    k.master = a.master; k.qn = a.qn; k.K = a.K; k.B = a.B; k.k = a.k;
+    k.cos_out = a.cos_out; k.id_out = a.id_out; k.id_base = a.id_base;
+    hipLaunchKernelGGL(select_rescore_kernel, dim3(a.B), dim3(SEL_THREADS), 0, stream, k);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int P, int B, int k,
+                      float* cos_out, int64_t* id_out, hipStream_t stream) {
+    if (B <= 0) return SQE_OK;
+    if (P < 1 || k < 1) return fail(SQE_ERR_INVALID, "merge: P and k must be >= 1");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, stream, cos_parts, id_parts, P, B, k,
+                       cos_out, id_out);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+}  // namespace sqe

@@ -1,0 +1,210 @@
+"""Thin object layer over the C ABI (include/sqe.h): Context, VectorIndex, CacheMatrix.
+
+NumPy in / NumPy out for host callers; raw device pointers (``tensor.data_ptr()``) for
+callers that already hold their data in HBM.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+INDEX_FLAT = 0
+INDEX_IVF_FLAT = 1
+SCAN_BF16_RESCORE = 0
+SCAN_FP32 = 1
+
+
+def _f32(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """One MI355X device (one process per GPU; ``device`` is the local HIP ordinal)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = N.load()
+        ids = (C.c_int32 * 1)(device)
+        h = C.c_void_p()
+        N.check(self.lib.sqe_create(ids, 1, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.sqe_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self) -> None:
+        N.check(self.lib.sqe_synchronize(self.handle))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.sqe_stream(self.handle) or 0)
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cu = C.c_int32()
+        mem = C.c_int64()
+        N.check(self.lib.sqe_device_info(self.handle, name, 128, C.byref(cu), C.byref(mem)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    def set_profiling(self, on: bool) -> None:
+        N.check(self.lib.sqe_set_profiling(self.handle, int(on)))
+
+    def stats(self) -> dict:
+        s = N.Stats()
+        N.check(self.lib.sqe_stats(self.handle, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in N.Stats._fields_}
+
+    def stats_reset(self) -> None:
+        N.check(self.lib.sqe_stats_reset(self.handle))
+
+    # -- cache scan, one-shot (main.py:73-87)
+    def cosine_best(self, mat: np.ndarray, q: np.ndarray) -> Tuple[float, int]:
+        mat = _f32(mat).reshape(-1, q.shape[-1]) if mat.size else np.zeros((0, q.shape[-1]), np.float32)
+        q = _f32(q).reshape(-1)
+        sim = C.c_float()
+        idx = C.c_int32()
+        N.check(self.lib.sqe_cosine_best(self.handle, mat.ctypes.data, mat.shape[0], q.shape[0],
+                                         q.ctypes.data, C.byref(sim), C.byref(idx)))
+        return float(sim.value), int(idx.value)
+
+    def cosine_all(self, mat: np.ndarray, q: np.ndarray) -> np.ndarray:
+        q = _f32(q).reshape(-1)
+        mat = _f32(mat).reshape(-1, q.shape[0])
+        out = np.empty(mat.shape[0], np.float32)
+        N.check(self.lib.sqe_cosine_all(self.handle, mat.ctypes.data, mat.shape[0], q.shape[0],
+                                        q.ctypes.data, out.ctypes.data))
+        return out
+
+    def merge_topk_device(self, cos_parts_ptr: int, id_parts_ptr: int, P: int, B: int, k: int,
+                          cos_out_ptr: int, id_out_ptr: int) -> None:
+        N.check(self.lib.sqe_merge_topk_device(self.handle, cos_parts_ptr, id_parts_ptr, P, B, k,
+                                               cos_out_ptr, id_out_ptr))
+
+
+class VectorIndex:
+    """Cosine index over ``dim``-d vectors held in HBM (fp32 master + bf16 scanned copy)."""
+
+    def __init__(self, ctx: Context, dim: int = 1024, kind: int = INDEX_FLAT, nlist: int = 0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.dim = dim
+        h = C.c_void_p()
+        N.check(self.lib.sqe_index_create(ctx.handle, dim, kind, nlist, C.byref(h)))
+        self.handle = h
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.sqe_index_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_int64()
+        N.check(self.lib.sqe_index_count(self.handle, C.byref(n)))
+        return int(n.value)
+
+    def reserve(self, rows: int) -> None:
+        N.check(self.lib.sqe_index_reserve(self.handle, rows))
+
+    def set_option(self, key: str, value: float) -> None:
+        N.check(self.lib.sqe_index_set_option(self.handle, key.encode(), float(value)))
+
+    def add(self, x: np.ndarray) -> None:
+        x = _f32(x)
+        if x.size == 0:
+            return
+        if x.ndim != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"expected [n, {self.dim}] array, got {x.shape}")
+        N.check(self.lib.sqe_index_add(self.handle, x.ctypes.data, x.shape[0]))
+
+    def add_device(self, ptr: int, n: int) -> None:
+        N.check(self.lib.sqe_index_add_device(self.handle, ptr, n))
+
+    def update(self, rows: np.ndarray, x: np.ndarray) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        x = _f32(x)
+        if rows.size:
+            N.check(self.lib.sqe_index_update(self.handle, rows.ctypes.data, x.ctypes.data, rows.shape[0]))
+
+    def get_rows(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((rows.shape[0], self.dim), np.float32)
+        if rows.size:
+            N.check(self.lib.sqe_index_get_rows(self.handle, rows.ctypes.data, rows.shape[0], out.ctypes.data))
+        return out
+
+    def search(self, q: np.ndarray, k: int, nprobe: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (cos [B,k] float32, ids [B,k] int64), best first, ties to the lowest id,
+        (-inf, -1) padded."""
+        q = _f32(q)
+        if q.ndim == 1:
+            q = q[None]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"expected [B, {self.dim}] queries, got {q.shape}")
+        b = q.shape[0]
+        cos = np.empty((b, k), np.float32)
+        ids = np.empty((b, k), np.int64)
+        if b:
+            N.check(self.lib.sqe_index_search(self.handle, q.ctypes.data, b, k, nprobe,
+                                              cos.ctypes.data, ids.ctypes.data))
+        return cos, ids
+
+    def search_device(self, q_ptr: int, b: int, k: int, cos_ptr: int, id_ptr: int, nprobe: int = 0) -> None:
+        """Asynchronous on the context stream; all pointers are device pointers."""
+        N.check(self.lib.sqe_index_search_device(self.handle, q_ptr, b, k, nprobe, cos_ptr, id_ptr))
+
+
+class CacheMatrix:
+    """Resident cache matrix for the lfu_cache_get scan (main.py:73-87): slots hold raw
+    embeddings; ``best(order, q)`` returns (sim, list position) of the first strict max."""
+
+    def __init__(self, ctx: Context, capacity: int, dim: int = 1024):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.capacity, self.dim = capacity, dim
+        h = C.c_void_p()
+        N.check(self.lib.sqe_cache_create(ctx.handle, capacity, dim, C.byref(h)))
+        self.handle = h
+        self._lock = threading.Lock()
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.sqe_cache_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_slot(self, slot: int, vec: np.ndarray) -> None:
+        vec = _f32(vec).reshape(-1)
+        N.check(self.lib.sqe_cache_set_slot(self.handle, slot, vec.ctypes.data))
+
+    def best(self, order, q: np.ndarray) -> Tuple[float, int]:
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        q = _f32(q).reshape(-1)
+        sim = C.c_float()
+        pos = C.c_int32()
+        N.check(self.lib.sqe_cache_best(self.handle, order.ctypes.data, order.shape[0], q.ctypes.data,
+                                        C.byref(sim), C.byref(pos)))
+        return float(sim.value), int(pos.value)

@@ -1,0 +1,147 @@
+"""Parity of the HIP search path (through the C ABI) against the oracle.  GPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import retrieval as R
+from tests import golden_cases as G
+from tests.gpu_util import assert_topk_matches, exact_topk_fast
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from semantic_query_engine_amd import Context
+    c = Context(0)
+    info = c.device_info()
+    assert info["cu_count"] >= 64
+    return c
+
+
+def _index(ctx, x, dim=None):
+    from semantic_query_engine_amd import VectorIndex
+    idx = VectorIndex(ctx, dim or x.shape[1])
+    idx.add(x)
+    return idx
+
+
+def test_normalize_matches_reference_golden(ctx, golden_dir):
+    exp = np.load(os.path.join(golden_dir, "normalize_rows.npz"))["expected"]
+    e = G.normalize_case()
+    idx = _index(ctx, e)
+    got = idx.get_rows(np.arange(32))
+    assert not np.isnan(got).any() and np.all(got[3] == 0.0)
+    big = np.abs(exp) > 1e-30
+    assert np.allclose(got[big], exp[big], rtol=5e-7, atol=0)     # fp32 sum order: a few ulp
+    assert np.allclose(got, exp, rtol=5e-7, atol=1e-37)
+
+
+def test_knn_golden_small(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "knn_small.npz"))
+    x, q = G.knn_case()
+    idx = _index(ctx, x)
+    assert len(idx) == 4096
+    cos, ids = idx.search(q, 10)
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    assert_topk_matches(cos, ids, g["cos"], g["ids"], xn, qn)
+    assert ids[0].tolist() == [5] + list(range(3000, 3009))       # 41-way exact tie -> lowest ids
+    assert ids[15].tolist() == list(range(10))                    # zero query: all cosines 0
+    # single-query calls (the reference's B=1 pattern, main.py:355) give the same answers
+    for b in (0, 3, 15):
+        c1, i1 = idx.search(q[b:b + 1], 10)
+        assert np.array_equal(i1[0], ids[b]) and np.allclose(c1[0], cos[b], atol=1e-6)
+
+
+@pytest.mark.parametrize("n,b,k", [(1, 1, 3), (7, 3, 10), (255, 2, 5), (257, 65, 10), (1000, 64, 1),
+                                   (5000, 130, 10), (20011, 37, 32), (3000, 300, 100)])
+def test_shapes_and_edges(ctx, n, b, k):
+    rng = np.random.default_rng(n * 31 + b)
+    x = rng.standard_normal((n, 256)).astype(np.float32)
+    q = rng.standard_normal((b, 256)).astype(np.float32)
+    q[0] = x[n // 2] * 3.0 + 0.01 * q[0]
+    idx = _index(ctx, x)
+    cos, ids = idx.search(q, k)
+    ref_cos, ref_ids = R.knn_search(x, q, k)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    assert ids[0, 0] == n // 2
+    if k > n:
+        assert np.all(ids[:, n:] == -1) and np.all(np.isneginf(cos[:, n:]))
+
+
+def test_empty_index_and_incremental_add(ctx):
+    from semantic_query_engine_amd import VectorIndex
+    rng = np.random.default_rng(2)
+    idx = VectorIndex(ctx, 128)
+    q = rng.standard_normal((3, 128)).astype(np.float32)
+    cos, ids = idx.search(q, 4)
+    assert np.all(ids == -1) and np.all(np.isneginf(cos))
+    x = rng.standard_normal((3000, 128)).astype(np.float32)
+    for lo, hi in [(0, 1), (1, 300), (300, 1500), (1500, 3000)]:      # grows across reallocation
+        idx.add(x[lo:hi])
+    assert len(idx) == 3000
+    cos, ids = idx.search(q, 4)
+    ref_cos, ref_ids = R.knn_search(x, q, 4)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    # overwrite rows in place (re-indexing an existing _id)
+    x[10] = q[0] * 2.0
+    x[2000] = -q[1]
+    idx.update(np.array([10, 2000]), x[[10, 2000]])
+    cos, ids = idx.search(q, 4)
+    ref_cos, ref_ids = R.knn_search(x, q, 4)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    assert ids[0, 0] == 10 and abs(cos[0, 0] - 1.0) < 1e-6
+
+
+def test_adversarial_orderings(ctx):
+    """Scores that increase with the row id defeat the running threshold (every row is a
+    candidate, maximum compaction load); all-equal rows are one giant tie."""
+    n, d = 30000, 64
+    theta = np.linspace(1.5, 0.0, n)
+    x = np.zeros((n, d), np.float32)
+    x[:, 0], x[:, 1] = np.cos(theta), np.sin(theta)
+    q = np.zeros((2, d), np.float32)
+    q[0, 0] = 1.0                 # ascending scores
+    q[1, 1] = 1.0                 # descending scores
+    idx = _index(ctx, x)
+    cos, ids = idx.search(q, 10)
+    ref_cos, ref_ids = R.knn_search(x, q, 10)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q), tol=1e-7)
+    same = np.tile(np.linspace(-1, 1, d, dtype=np.float32), (7000, 1))
+    idx2 = _index(ctx, same)
+    cos, ids = idx2.search(same[:3] * 5.0, 10)
+    assert np.array_equal(ids, np.tile(np.arange(10), (3, 1))) and np.allclose(cos, 1.0, atol=1e-6)
+
+
+def test_config2_shape_recall(ctx):
+    """BASELINE config 2 at reduced N (the oracle must finish in seconds): N=200k x 1024,
+    B=1024, k=10, recall@10 = 1.0 vs exact, cosines within 1e-3."""
+    rng = np.random.default_rng(0)
+    n, b = 200_000, 1024
+    x = rng.standard_normal((n, 1024), dtype=np.float32)
+    q = rng.standard_normal((b, 1024), dtype=np.float32)
+    plant = rng.integers(0, n, b // 2)
+    q[: b // 2] = x[plant] + 0.1 * q[: b // 2]
+    idx = _index(ctx, x)
+    cos, ids = idx.search(q, 10)
+    ref_cos, ref_ids = exact_topk_fast(x, q, 10)
+    assert R.recall_at_k(ids, ref_ids) == 1.0
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    assert np.array_equal(ids[: b // 2, 0], plant)
+    assert np.abs(cos - ref_cos).max() < 1e-5
+
+
+def test_profiling_stats(ctx):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((4096, 1024)).astype(np.float32)
+    idx = _index(ctx, x)
+    ctx.stats_reset()
+    ctx.set_profiling(True)
+    for _ in range(3):
+        idx.search(x[:8], 10)
+    st = ctx.stats()
+    ctx.set_profiling(False)
+    assert st["scan_calls"] == 3 and st["search_calls"] == 3 and st["scan_ms"] > 0
+    assert st["scan_flops"] == 2 * 4096 * 1024 * 8 and st["scan_rows"] == 4096
