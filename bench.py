@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Headline benchmark: brute-force cosine k-NN queries/sec over 10M x 1024-d vectors, top-10.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of B synthetic queries that are
+already resident in HBM: sqe_index_search_device (query normalise + bf16 MFMA scan with
+fused top-k filter + fp32 rescore) and, for N > 1, the all-gather of per-shard top-k over
+RCCL plus the merge kernel.  The 10M-row index is sharded row-wise across the N ranks
+(strong scaling: the job is "answer B queries over the 10M-row index").
+
+Rank 0 prints ONE JSON line (see the task contract); `roofline` is for the scan kernel
+(hipEvent-timed inside libsqe on the stream it runs on), `cpu_baseline` is the NumPy
+oracle (OpenBLAS sgemm + argpartition, all host cores) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+D = 1024
+BLOCK_ROWS = 1 << 20          # DB is generated in blocks of 1M rows, seed = base + block
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0
+
+
+def db_block(block: int, rows: int, device, seed: int = 1000) -> torch.Tensor:
+    g = torch.Generator(device=device).manual_seed(seed + block)
+    return torch.randn((rows, D), generator=g, device=device, dtype=torch.float32)
+
+
+def make_queries(b: int, device, seed: int = 12345) -> torch.Tensor:
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.randn((b, D), generator=g, device=device, dtype=torch.float32)
+
+
+def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
+    """NumPy oracle timed on the host cores, on a bounded sample of the same workload:
+    fp32 normalise + Q @ X.T (OpenBLAS) + argpartition top-k over `sample_rows` rows,
+    scaled linearly in N to the full index."""
+    from oracle import retrieval as R
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((sample_rows, D), dtype=np.float32)
+    q = rng.standard_normal((b, D), dtype=np.float32)
+    xn = R.normalize_rows(x)
+    t0 = time.perf_counter()
+    qn = R.normalize_rows(q)
+    blk = 65536
+    best = None
+    for lo in range(0, sample_rows, blk):
+        s = qn @ xn[lo:lo + blk].T
+        part = np.argpartition(-s, k, axis=1)[:, :k]
+        vals = np.take_along_axis(s, part, 1)
+        cur = (vals, part + lo)
+        if best is None:
+            best = cur
+        else:
+            v = np.concatenate([best[0], cur[0]], 1)
+            i = np.concatenate([best[1], cur[1]], 1)
+            o = np.argpartition(-v, k, axis=1)[:, :k]
+            best = (np.take_along_axis(v, o, 1), np.take_along_axis(i, o, 1))
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    qps = b / (dt * (n_total / sample_rows))
+    return {"value": round(qps, 3), "unit": "queries/s", "cores": int(threads), "kind": "port",
+            "sample": f"numpy oracle (fp32 sgemm + argpartition top-{k}), {sample_rows} rows x {b} queries "
+                      f"in {dt:.2f}s, scaled linearly to {n_total} rows"}
+
+
+def exact_reference(q: torch.Tensor, n_total: int, row_lo: int, row_hi: int, k: int, device):
+    """Independent exact top-k (torch fp32 matmul over regenerated blocks) for the recall check."""
+    qn = q / (q.norm(dim=1, keepdim=True) + 1e-9)
+    best_s = torch.full((q.shape[0], 0), -float("inf"), device=device)
+    best_i = torch.zeros((q.shape[0], 0), dtype=torch.long, device=device)
+    nblocks = (n_total + BLOCK_ROWS - 1) // BLOCK_ROWS
+    for blk in range(nblocks):
+        lo = blk * BLOCK_ROWS
+        hi = min(n_total, lo + BLOCK_ROWS)
+        if hi <= row_lo or lo >= row_hi:
+            continue
+        x = db_block(blk, hi - lo, device)
+        a, b_ = max(lo, row_lo) - lo, min(hi, row_hi) - lo
+        x = x[a:b_]
+        xn = x / (x.norm(dim=1, keepdim=True) + 1e-9)
+        s = qn @ xn.T
+        ids = torch.arange(lo + a, lo + b_, device=device).expand_as(s)
+        s = torch.cat([best_s, s], 1)
+        ids = torch.cat([best_i, ids], 1)
+        top = torch.topk(s, min(k, s.shape[1]), dim=1)
+        best_s, best_i = top.values, torch.gather(ids, 1, top.indices)
+        del x, xn, s, ids
+    return best_s, best_i
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (all ranks)")
+    ap.add_argument("--batch", type=int, default=1024, help="queries per step")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--recall-queries", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=device)
+
+    from semantic_query_engine_amd import Context, VectorIndex
+    from semantic_query_engine_amd.sharded import ShardedSearcher
+
+    ctx = Context(local_rank)
+    n_total, b, k = args.rows, args.batch, args.k
+    rows_per = (n_total + world - 1) // world
+    row_lo, row_hi = rank * rows_per, min(n_total, (rank + 1) * rows_per)
+
+    # ---- build this rank's shard in HBM (seeded blocks, never through host memory)
+    idx = VectorIndex(ctx, D)
+    idx.reserve(row_hi - row_lo)
+    nblocks = (n_total + BLOCK_ROWS - 1) // BLOCK_ROWS
+    for blk in range(nblocks):
+        lo = blk * BLOCK_ROWS
+        hi = min(n_total, lo + BLOCK_ROWS)
+        if hi <= row_lo or lo >= row_hi:
+            continue
+        x = db_block(blk, hi - lo, device)
+        a, e = max(lo, row_lo) - lo, min(hi, row_hi) - lo
+        xs = x[a:e].contiguous()
+        torch.cuda.synchronize()
+        idx.add_device(xs.data_ptr(), xs.shape[0])
+        ctx.synchronize()
+        del x, xs
+    assert len(idx) == row_hi - row_lo
+    torch.cuda.empty_cache()
+
+    q = make_queries(b, device)
+    # plant true neighbours for half the queries so recall is non-trivial
+    plant_rows = torch.arange(0, b // 2, device=device) * (n_total // max(b // 2, 1))
+    for blk in range(nblocks):
+        lo, hi = blk * BLOCK_ROWS, min(n_total, (blk + 1) * BLOCK_ROWS)
+        sel = (plant_rows >= lo) & (plant_rows < hi)
+        if sel.any():
+            x = db_block(blk, hi - lo, device)
+            qi = torch.nonzero(sel).flatten()
+            q[qi] = x[plant_rows[qi] - lo] + 0.1 * q[qi]
+            del x
+    torch.cuda.synchronize()
+
+    searcher = ShardedSearcher(ctx, idx, id_base=row_lo, dist=dist, world=world, device=device)
+
+    def step():
+        return searcher.search(q, k)
+
+    for _ in range(args.warmup):
+        step()
+    searcher.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.stats_reset()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cos, ids = step()
+    searcher.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was timed: recall@k vs an independent exact scan
+    nq = min(args.recall_queries, b)
+    probe = torch.cat([torch.arange(0, nq // 2), torch.arange(b - (nq - nq // 2), b)]).to(device)
+    ref_s, ref_i = exact_reference(q[probe], n_total, row_lo, row_hi, k, device)
+    if dist is not None:
+        gs = [torch.empty_like(ref_s) for _ in range(world)]
+        gi = [torch.empty_like(ref_i) for _ in range(world)]
+        dist.all_gather(gs, ref_s)
+        dist.all_gather(gi, ref_i)
+        s_all, i_all = torch.cat(gs, 1), torch.cat(gi, 1)
+        top = torch.topk(s_all, k, dim=1)
+        ref_s, ref_i = top.values, torch.gather(i_all, 1, top.indices)
+    got_i = ids[probe]
+    got_s = cos[probe]
+    hits = sum(len(set(a.tolist()) & set(r.tolist())) for a, r in zip(got_i.cpu(), ref_i.cpu()))
+    recall = hits / (nq * k)
+    max_dcos = float((got_s - ref_s).abs().max().item())
+    planted_ok = bool((ids[: b // 2, 0] == plant_rows).all().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = b * args.steps / elapsed
+        scan_ms = st["scan_ms"] / max(st["scan_calls"], 1)
+        flops = float(st["scan_flops"])
+        bytes_ = float(st["scan_bytes"])
+        tflops = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+        gbps = bytes_ / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        # binding roof: the scan needs max(flops/peak_mfma, bytes/peak_hbm) at best
+        t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), bytes_ / (PEAK_HBM_GBPS * 1e9)
+        if t_mfma >= t_hbm:
+            roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": None}
+        else:
+            roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None}
+        roof.update({"kernel": "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
+                     "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
+                     "hbm_gbps": round(gbps, 1), "mfma_tflops": round(tflops, 2)})
+        out = {
+            "metric": "k-NN queries/sec (brute-force cosine top-10, 1024-d, 10M vectors)",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"flat cosine top-{k}, N={n_total} x {D} fp32 (bf16 scan + fp32 rescore), "
+                                   f"batch={b} queries/step, index row-sharded over {world} GPU(s)",
+                       "rows": n_total, "dim": D, "batch": b, "k": k, "parallelism": f"shard{world}"},
+            "recall_at_10": round(recall, 4), "max_abs_dcos": max_dcos, "planted_top1_ok": planted_ok,
+            "stage_ms": {"prep": round(st["prep_ms"] / args.steps, 4), "scan": round(scan_ms, 4),
+                         "select_rescore": round(st["select_ms"] / args.steps, 4)},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, b, n_total, k)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

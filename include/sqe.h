@@ -61,6 +61,10 @@ void sqe_destroy(sqe_ctx* ctx);
 int sqe_synchronize(sqe_ctx* ctx);
 /* hipStream_t the "_device" entry points enqueue on (for event timing by the caller). */
 void* sqe_stream(sqe_ctx* ctx);
+/* Make the context enqueue on a caller-owned hipStream_t (e.g. torch's current stream, so
+ * collectives and library kernels order without host synchronisation); NULL restores the
+ * context's own stream.  The caller keeps the stream alive while it is set. */
+int sqe_set_stream(sqe_ctx* ctx, void* hip_stream);
 int sqe_device_info(sqe_ctx* ctx, char* name, int name_cap, int* cu_count, int64_t* hbm_bytes);
 
 /* ---- vector index: stands behind OpenSearchIndexer (main.py:291-373) ------------- */
@@ -83,7 +87,8 @@ int sqe_index_count(const sqe_index* idx, int64_t* out);
 int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, float* out_host);
 
 /* Options: "scan_mode" (SQE_SCAN_*), "rescore_k" (candidates kept by the bf16 scan,
- * 0 = automatic), "nprobe" default for IVF. */
+ * 0 = automatic), "nprobe" default for IVF, "id_base" (added to every returned row id:
+ * the first global row of this shard in a row-sharded index). */
 int sqe_index_set_option(sqe_index* idx, const char* key, double value);
 
 /* search (main.py:347-373): q is [B, dim] row-major raw query embeddings; each is
@@ -101,11 +106,14 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
 int sqe_index_train(sqe_index* idx, const float* x_host, int64_t n, int iters, uint64_t seed);
 int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int iters, uint64_t seed);
 
-/* Merge of per-shard results after the all-gather of a row-sharded index: parts are
- * [P, B, k] (cos fp32, global ids int64, -1 padded); out is [B, k], best first, ties to
- * the lowest id.  Device pointers, context stream. */
+/* Merge of per-shard results after the all-gather of a row-sharded index: part p holds
+ * cos [B,k] fp32 at cos_parts_dev + p * part_stride_bytes and global ids [B,k] int64
+ * (-1 padded) at id_parts_dev + p * part_stride_bytes (part_stride_bytes = 0: dense
+ * [P,B,k] arrays).  out is [B,k], best first, ties to the lowest id.  Device pointers,
+ * context stream. */
 int sqe_merge_topk_device(sqe_ctx* ctx, const float* cos_parts_dev, const int64_t* id_parts_dev,
-                          int P, int B, int k, float* cos_out_dev, int64_t* id_out_dev);
+                          int64_t part_stride_bytes, int P, int B, int k,
+                          float* cos_out_dev, int64_t* id_out_dev);
 
 /* ---- semantic cache scan: stands behind the loop of lfu_cache_get (main.py:73-87) -- */
 /* One-shot form: mat is [m, dim] raw (un-normalised) cached embeddings in list order

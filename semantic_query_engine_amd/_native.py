@@ -38,6 +38,7 @@ SIGNATURES = {
     "sqe_destroy": (None, [C.c_void_p]),
     "sqe_synchronize": (C.c_int, [C.c_void_p]),
     "sqe_stream": (C.c_void_p, [C.c_void_p]),
+    "sqe_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqe_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_i32_p, c_i64_p]),
     "sqe_index_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sqe_index_destroy": (None, [C.c_void_p]),
@@ -52,7 +53,7 @@ SIGNATURES = {
     "sqe_index_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sqe_index_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64]),
     "sqe_index_train_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64]),
-    "sqe_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sqe_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sqe_cosine_best": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_float_p, c_i32_p]),
     "sqe_cosine_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sqe_cache_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

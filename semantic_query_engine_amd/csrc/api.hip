@@ -104,7 +104,8 @@ using namespace sqe;
 // ================================================================ objects
 struct sqe_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream in use
+    hipStream_t own_stream = nullptr;   // created by sqe_create
     std::recursive_mutex mu;
     int cu_count = 256;
     int64_t hbm_bytes = 0;
@@ -128,6 +129,7 @@ struct sqe_index {
     int scan_mode = SQE_SCAN_BF16_RESCORE;
     int rescore_k = 0;             // 0 = automatic
     int nprobe = 0;
+    int64_t id_base = 0;           // added to returned ids (row-sharded index)
     DevBuf qn;                     // [B, dim] fp32 normalised queries
     DevBuf qb;                     // [b_pad, dim] bf16 queries
     DevBuf cand;                   // [n_chunks, b_pad, CAND_CAP] u64
@@ -212,10 +214,11 @@ int sqe_create(const int* device_ids, int n_dev, sqe_ctx** out) {
     SQE_HIP(hipGetDeviceProperties(&prop, c->device));
     c->cu_count = prop.multiProcessorCount;
     c->hbm_bytes = (int64_t)prop.totalGlobalMem;
-    c->name = prop.name;
+    c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(SQE_ERR_UNSUPPORTED, std::string("libsqe is built for gfx950 only, device is ") + prop.gcnArchName);
-    SQE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SQE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     *out = c.release();
     return SQE_OK;
 }
@@ -223,10 +226,9 @@ int sqe_create(const int* device_ids, int n_dev, sqe_ctx** out) {
 void sqe_destroy(sqe_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->prof.drain(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -237,6 +239,14 @@ int sqe_synchronize(sqe_ctx* ctx) {
 }
 
 void* sqe_stream(sqe_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sqe_set_stream(sqe_ctx* ctx, void* hip_stream) {
+    SQE_ENTER(ctx);
+    ctx->prof.drain(ctx->stream);
+    SQE_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SQE_OK;
+}
 
 int sqe_device_info(sqe_ctx* ctx, char* name, int name_cap, int* cu_count, int64_t* hbm_bytes) {
     SQE_ENTER(ctx);
@@ -374,6 +384,9 @@ int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
         idx->rescore_k = (int)value;
     } else if (k == "nprobe") {
         idx->nprobe = (int)value;
+    } else if (k == "id_base") {
+        if (value < 0) return fail(SQE_ERR_INVALID, "id_base must be >= 0");
+        idx->id_base = (int64_t)value;
     } else {
         return fail(SQE_ERR_INVALID, "unknown option: " + k);
     }
@@ -418,7 +431,7 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         s.cand = idx->cand.as<uint64_t>(); s.cand_cnt = idx->cand_cnt.as<int>();
         s.n_chunks = plan.n_chunks; s.b_pad = plan.b_pad; s.kp = kp;
         s.master = idx->master; s.qn = idx->qn.as<float>(); s.K = K; s.B = B; s.k = k;
-        s.cos_out = cos_out_dev; s.id_out = id_out_dev; s.id_base = 0;
+        s.cos_out = cos_out_dev; s.id_out = id_out_dev; s.id_base = idx->id_base;
         SQE_TRY(launch_select_rescore(s, c->stream));
     }
     c->search_calls++;
@@ -459,11 +472,13 @@ int sqe_index_train_device(sqe_index* idx, const float*, int64_t, int, uint64_t)
 }
 
 int sqe_merge_topk_device(sqe_ctx* ctx, const float* cos_parts_dev, const int64_t* id_parts_dev,
-                          int P, int B, int k, float* cos_out_dev, int64_t* id_out_dev) {
+                          int64_t part_stride_bytes, int P, int B, int k,
+                          float* cos_out_dev, int64_t* id_out_dev) {
     SQE_ENTER(ctx);
     if (!cos_parts_dev || !id_parts_dev || !cos_out_dev || !id_out_dev)
         return fail(SQE_ERR_INVALID, "sqe_merge_topk: null buffer");
-    return launch_merge_topk(cos_parts_dev, id_parts_dev, P, B, k, cos_out_dev, id_out_dev, ctx->stream);
+    if (part_stride_bytes < 0 || part_stride_bytes % 8 != 0) return fail(SQE_ERR_INVALID, "sqe_merge_topk: bad part stride");
+    return launch_merge_topk(cos_parts_dev, id_parts_dev, part_stride_bytes, P, B, k, cos_out_dev, id_out_dev, ctx->stream);
 }
 
 // ================================================================ cache scan

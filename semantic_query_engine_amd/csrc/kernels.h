@@ -57,8 +57,8 @@ struct SelectArgs {
 int launch_select_rescore(const SelectArgs& args, hipStream_t stream);
 
 // merge of [P,B,k] partial results (multi-GPU all-gather output)
-int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int P, int B, int k,
-                      float* cos_out, int64_t* id_out, hipStream_t stream);
+int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,
+                      int P, int B, int k, float* cos_out, int64_t* id_out, hipStream_t stream);
 
 // ------------------------------------------------------------------ cache scan (S8)
 // sims[i] = cosine(mat[slot(i)], q) with the zero-norm rule; slot(i) = order ? order[i] : i.

@@ -133,25 +133,34 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
 }
 
 // ---- merge of P partial top-k lists per query (after the all-gather of a sharded index)
-__global__ __launch_bounds__(64) void merge_topk_kernel(const float* __restrict__ cos_parts,
-                                                        const int64_t* __restrict__ id_parts,
+__global__ __launch_bounds__(64) void merge_topk_kernel(const char* __restrict__ cos_parts,
+                                                        const char* __restrict__ id_parts,
+                                                        int64_t cos_stride, int64_t id_stride,
                                                         int P, int B, int k,
                                                         float* __restrict__ cos_out,
                                                         int64_t* __restrict__ id_out) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
     const int total = P * k;
-    // rank by counting: entry e = (part, j) beats f when cos higher, or equal cos and lower id
-    for (int e = lane; e < total; e += 64) {
+    auto score = [&](int e) {
         const int part = e / k, j = e - part * k;
-        const float se = cos_parts[((size_t)part * B + q) * k + j];
-        const int64_t ie = id_parts[((size_t)part * B + q) * k + j];
+        return reinterpret_cast<const float*>(cos_parts + part * cos_stride)[(size_t)q * k + j];
+    };
+    auto ident = [&](int e) {
+        const int part = e / k, j = e - part * k;
+        return reinterpret_cast<const int64_t*>(id_parts + part * id_stride)[(size_t)q * k + j];
+    };
+    // rank by counting: entry e beats f when cos higher, or equal cos and lower id
+    int valid = 0;
+    for (int e = lane; e < total; e += 64) {
+        const float se = score(e);
+        const int64_t ie = ident(e);
         if (ie < 0) continue;
+        ++valid;
         int rank = 0;
         for (int f = 0; f < total; ++f) {
-            const int pf = f / k, jf = f - pf * k;
-            const float sf = cos_parts[((size_t)pf * B + q) * k + jf];
-            const int64_t idf = id_parts[((size_t)pf * B + q) * k + jf];
+            const float sf = score(f);
+            const int64_t idf = ident(f);
             if (f == e || idf < 0) continue;
             const bool better = (se != se) ? (sf == sf || idf < ie) : (sf > se || (sf == se && idf < ie));
             rank += better ? 1 : 0;
@@ -160,12 +169,6 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const float* __restrict_
             cos_out[(size_t)q * k + rank] = se;
             id_out[(size_t)q * k + rank] = ie;
         }
-    }
-    // pad: number of valid entries
-    int valid = 0;
-    for (int e = lane; e < total; e += 64) {
-        const int part = e / k, j = e - part * k;
-        valid += id_parts[((size_t)part * B + q) * k + j] >= 0 ? 1 : 0;
     }
     for (int off = 32; off > 0; off >>= 1) valid += __shfl_xor(valid, off, 64);
     for (int i = valid + lane; i < k; i += 64) {
@@ -189,12 +192,15 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
     return SQE_OK;
 }
 
-int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int P, int B, int k,
-                      float* cos_out, int64_t* id_out, hipStream_t stream) {
+int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,
+                      int P, int B, int k, float* cos_out, int64_t* id_out, hipStream_t stream) {
     if (B <= 0) return SQE_OK;
     if (P < 1 || k < 1) return fail(SQE_ERR_INVALID, "merge: P and k must be >= 1");
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, stream, cos_parts, id_parts, P, B, k,
-                       cos_out, id_out);
+    const int64_t cs = part_stride_bytes ? part_stride_bytes : (int64_t)B * k * 4;
+    const int64_t is = part_stride_bytes ? part_stride_bytes : (int64_t)B * k * 8;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, stream,
+                       reinterpret_cast<const char*>(cos_parts), reinterpret_cast<const char*>(id_parts),
+                       cs, is, P, B, k, cos_out, id_out);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

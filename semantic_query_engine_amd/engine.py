@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import weakref
 from typing import Optional, Tuple
 
 import numpy as np
@@ -33,9 +34,12 @@ class Context:
         N.check(self.lib.sqe_create(ids, 1, C.byref(h)))
         self.handle = h
         self.device = device
+        self._children = weakref.WeakSet()      # indexes / caches that must die first
 
     def close(self) -> None:
         if getattr(self, "handle", None):
+            for child in list(self._children):
+                child.close()
             self.lib.sqe_destroy(self.handle)
             self.handle = None
 
@@ -51,6 +55,11 @@ class Context:
     @property
     def stream(self) -> int:
         return int(self.lib.sqe_stream(self.handle) or 0)
+
+    def set_stream(self, hip_stream: int) -> None:
+        """Enqueue on a caller-owned stream (e.g. ``torch.cuda.current_stream().cuda_stream``);
+        0 restores the context's own stream."""
+        N.check(self.lib.sqe_set_stream(self.handle, hip_stream or None))
 
     def device_info(self):
         name = C.create_string_buffer(128)
@@ -88,10 +97,10 @@ class Context:
                                         q.ctypes.data, out.ctypes.data))
         return out
 
-    def merge_topk_device(self, cos_parts_ptr: int, id_parts_ptr: int, P: int, B: int, k: int,
-                          cos_out_ptr: int, id_out_ptr: int) -> None:
-        N.check(self.lib.sqe_merge_topk_device(self.handle, cos_parts_ptr, id_parts_ptr, P, B, k,
-                                               cos_out_ptr, id_out_ptr))
+    def merge_topk_device(self, cos_parts_ptr: int, id_parts_ptr: int, part_stride_bytes: int,
+                          P: int, B: int, k: int, cos_out_ptr: int, id_out_ptr: int) -> None:
+        N.check(self.lib.sqe_merge_topk_device(self.handle, cos_parts_ptr, id_parts_ptr, part_stride_bytes,
+                                               P, B, k, cos_out_ptr, id_out_ptr))
 
 
 class VectorIndex:
@@ -104,10 +113,12 @@ class VectorIndex:
         h = C.c_void_p()
         N.check(self.lib.sqe_index_create(ctx.handle, dim, kind, nlist, C.byref(h)))
         self.handle = h
+        ctx._children.add(self)
 
     def close(self) -> None:
         if getattr(self, "handle", None):
-            self.lib.sqe_index_destroy(self.handle)
+            if self.ctx.handle:                 # a destroyed context already released the device
+                self.lib.sqe_index_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -184,10 +195,12 @@ class CacheMatrix:
         N.check(self.lib.sqe_cache_create(ctx.handle, capacity, dim, C.byref(h)))
         self.handle = h
         self._lock = threading.Lock()
+        ctx._children.add(self)
 
     def close(self) -> None:
         if getattr(self, "handle", None):
-            self.lib.sqe_cache_destroy(self.handle)
+            if self.ctx.handle:
+                self.lib.sqe_cache_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -1,0 +1,67 @@
+"""Row-sharded search: one process per GPU, per-shard top-k, ONE exchange step.
+
+Every rank holds rows [id_base, id_base + len(index)) of the global index and the full
+query batch.  A search is: local scan + rescore -> [B,k] (cosine, GLOBAL id) -> one
+all-gather of the packed per-shard results over RCCL/xGMI (120 KB per rank at B=1024,
+k=10: latency-bound, so a single collective) -> merge kernel (ties to the lowest global
+id).  With world == 1 there is no collective.
+
+The library context is switched onto torch's current stream so the scan, the collective
+and the merge are ordered on the device without host synchronisation.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .engine import Context, VectorIndex
+
+
+def packed_part_bytes(b: int, k: int) -> int:
+    """Per-rank message: ids int64 [B,k] then cosines fp32 [B,k], padded to 16 bytes."""
+    return (b * k * 12 + 15) // 16 * 16
+
+
+class ShardedSearcher:
+    def __init__(self, ctx: Context, index: VectorIndex, id_base: int = 0, dist=None, world: int = 1,
+                 device: Optional[torch.device] = None, group=None):
+        self.ctx, self.index, self.dist, self.world, self.group = ctx, index, dist, world, group
+        self.device = device or torch.device("cuda", ctx.device)
+        index.set_option("id_base", float(id_base))
+        self._bufs = {}
+        # a dedicated torch stream (the default stream's handle is 0 = "no stream" to the ABI)
+        self.stream = torch.cuda.Stream(self.device)
+        ctx.set_stream(self.stream.cuda_stream)
+
+    def _buffers(self, b: int, k: int):
+        key = (b, k)
+        if key not in self._bufs:
+            part = packed_part_bytes(b, k)
+            local = torch.empty(part, dtype=torch.uint8, device=self.device)
+            gathered = torch.empty(part * self.world, dtype=torch.uint8, device=self.device) \
+                if self.world > 1 else local
+            cos = torch.empty((b, k), dtype=torch.float32, device=self.device)
+            ids = torch.empty((b, k), dtype=torch.int64, device=self.device)
+            self._bufs[key] = (part, local, gathered, cos, ids)
+        return self._bufs[key]
+
+    def search(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """q: [B, dim] fp32 on this rank's device (same batch on every rank).
+        Returns (cos [B,k] fp32, global ids [B,k] int64) on the device, asynchronously."""
+        b = q.shape[0]
+        part, local, gathered, cos, ids = self._buffers(b, k)
+        id_ptr = local.data_ptr()
+        cos_ptr = id_ptr + b * k * 8
+        with torch.cuda.stream(self.stream):
+            if self.world == 1:
+                self.index.search_device(q.data_ptr(), b, k, cos.data_ptr(), ids.data_ptr())
+                return cos, ids
+            self.index.search_device(q.data_ptr(), b, k, cos_ptr, id_ptr)
+            self.dist.all_gather_into_tensor(gathered, local, group=self.group)
+            g = gathered.data_ptr()
+            self.ctx.merge_topk_device(g + b * k * 8, g, part, self.world, b, k, cos.data_ptr(), ids.data_ptr())
+        return cos, ids
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()

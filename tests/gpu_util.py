@@ -38,7 +38,10 @@ def assert_topk_matches(cos, ids, ref_cos, ref_ids, xn=None, qn=None, tol=2e-6, 
     valid = ref_ids >= 0
     assert np.array_equal(ids >= 0, valid)
     assert np.all(np.abs(cos[valid] - ref_cos[valid]) < score_tol)          # north_star: 1e-3
-    assert np.all(np.diff(np.where(valid, cos, -np.inf), axis=1) <= 0)      # best first
+    for b in range(cos.shape[0]):                                            # best first
+        v = cos[b][valid[b]]
+        assert np.all(v[1:] <= v[:-1])
+    assert np.all(np.isneginf(cos[~valid]))
     bad = (ids != ref_ids) & valid
     for b, j in zip(*np.nonzero(bad)):
         assert xn is not None, f"ids differ at {(b, j)}: {ids[b]} vs {ref_ids[b]}"
