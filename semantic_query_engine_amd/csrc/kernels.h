@@ -41,6 +41,9 @@ struct ScanArgs {
     int* cand_cnt;        // [n_chunks, b_pad]
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
+// pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless
+// the environment sets SQE_SCAN_V0=1 (A/B and fallback).
+int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 
 // ------------------------------------------------------------------ select + rescore (S3+S4)
 struct SelectArgs {

@@ -22,32 +22,17 @@
 //
 // Candidate keys are (orderable(score) << 32) | (0xFFFFFFFF - row): one total order,
 // higher score first, lower row id first among equals, so results are deterministic.
-#include "kernels.h"
+#include <stdlib.h>
+
+#include "scan_common.h"
 
 namespace sqe {
 
 namespace {
 
-constexpr int THREADS = 512;
-constexpr int NWAVES = 8;
-constexpr int ROW_BYTES = SCAN_BK * 2;   // 128 B of bf16 per tile row per stage
-
-struct ScanKernelArgs {
-    const bf16_t* db;
-    const bf16_t* q;
-    int64_t n_rows;
-    int K;
-    int B;
-    int b_pad;
-    int n_tiles;
-    int tiles_per_chunk;
-    int n_chunks;
-    int qblocks;
-    int kp;
-    int trig;            // compaction trigger (kp <= trig <= CAND_CAP - SCAN_BM)
-    uint64_t* cand;
-    int* cand_cnt;
-};
+constexpr int THREADS = SCAN_THREADS;
+constexpr int NWAVES = SCAN_NWAVES;
+constexpr int ROW_BYTES = SCAN_ROW_BYTES;
 
 // Issue the global->LDS copy of `rows8 * 8` tile rows x 64 k (128 B per row) spread over
 // the 8 waves.  `gbase` points at (tile_row0, k0); `ld_bytes` is the global row pitch.
@@ -73,53 +58,6 @@ __device__ __forceinline__ void stage_tile(const char* gbase, size_t ld_bytes, c
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(tile + r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4));
-}
-
-// kp-th largest of the (unique, non-zero) keys held as k[j] by the wave; zero = empty.
-template <int NREG>
-__device__ __forceinline__ uint64_t wave_select_kth(const uint64_t (&k)[NREG], int nreg, int kth) {
-    uint64_t prefix = 0;
-    int remaining = kth;
-    for (int bit = 63; bit >= 0; --bit) {
-        const uint64_t trial = (prefix >> bit) | 1ull;
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < NREG; ++j)
-            if (j < nreg) c += __popcll(__ballot((k[j] >> bit) == trial));
-        if (c >= remaining) prefix |= (1ull << bit);
-        else remaining -= c;
-    }
-    return prefix;
-}
-
-// Wave-level compaction of one candidate list to its best `kp` keys; updates the
-// threshold of that query.  Caller guarantees n > kp.
-__device__ __forceinline__ void compact_list(uint64_t* list, int n, int kp, int lane,
-                                             int* cnt_slot, float* thr_s_slot, uint64_t* thr_key_slot) {
-    constexpr int NREG = CAND_CAP / 64;
-    const int nreg = (n + 63) >> 6;
-    uint64_t k[NREG];
-#pragma unroll
-    for (int j = 0; j < NREG; ++j) {
-        const int i = j * 64 + lane;
-        k[j] = (j < nreg && i < n) ? list[i] : 0ull;
-    }
-    const uint64_t T = wave_select_kth<NREG>(k, nreg, kp);
-    int base = 0;
-#pragma unroll
-    for (int j = 0; j < NREG; ++j) {
-        if (j < nreg) {
-            const bool keep = k[j] >= T && k[j] != 0ull;
-            const uint64_t m = __ballot(keep);
-            if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = k[j];
-            base += __popcll(m);
-        }
-    }
-    if (lane == 0) {
-        *cnt_slot = base;                // == kp
-        *thr_key_slot = T;
-        *thr_s_slot = key_score(T);
-    }
 }
 
 template <int WM, int WN, int FM, int FN>
@@ -256,19 +194,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             }
             __syncthreads();   // appends of this tile visible workgroup-wide
             // lists that could overflow on the next tile are cut back to their best kp
-            {
-                constexpr int PER_WAVE = BN / NWAVES;
-                static_assert(PER_WAVE <= 64, "one lane per owned query");
-                const int myq = wave * PER_WAVE + lane;
-                const bool need = lane < PER_WAVE && cnt[myq] >= p.trig;
-                uint64_t mask = __ballot(need);
-                while (mask) {
-                    const int bq = wave * PER_WAVE + (int)__builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    compact_list(cand_base + (size_t)bq * CAND_CAP, cnt[bq], p.kp, lane,
-                                 &cnt[bq], &thr_s[bq], &thr_key[bq]);
-                }
-            }
+            compact_owned(cand_base, wave * (BN / NWAVES), BN / NWAVES, p.trig, p.kp, lane, cnt, thr_s, thr_key);
         }
         ++ks;
         if (ks == KS) { ks = 0; ++tile; }
@@ -276,21 +202,10 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     }
 
     // final: every list down to <= kp entries, counts published
-    {
-        constexpr int PER_WAVE = BN / NWAVES;
-        const int myq = wave * PER_WAVE + lane;
-        const bool need = lane < PER_WAVE && cnt[myq] > p.kp;
-        uint64_t mask = __ballot(need);
-        while (mask) {
-            const int bq = wave * PER_WAVE + (int)__builtin_ctzll(mask);
-            mask &= mask - 1;
-            compact_list(cand_base + (size_t)bq * CAND_CAP, cnt[bq], p.kp, lane,
-                         &cnt[bq], &thr_s[bq], &thr_key[bq]);
-        }
-        __syncthreads();
-        for (int i = tid; i < BN; i += THREADS)
-            p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
-    }
+    compact_owned(cand_base, wave * (BN / NWAVES), BN / NWAVES, p.kp + 1, p.kp, lane, cnt, thr_s, thr_key);
+    __syncthreads();
+    for (int i = tid; i < BN; i += THREADS)
+        p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
 }
 
 template <int WM, int WN, int FM, int FN>
@@ -336,7 +251,11 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (a.K % SCAN_BK != 0) return fail(SQE_ERR_INVALID, "scan: dim must be a multiple of 64");
     if (plan.kp < 1 || plan.kp > MAX_KP) return fail(SQE_ERR_INVALID, "scan: kp out of range");
-    if (plan.bn == 256) return launch_cfg<2, 4, 8, 4>(plan, a, stream);
+    if (plan.bn == 256) {
+        static const bool use_v0 = [] { const char* e = getenv("SQE_SCAN_V0"); return e && e[0] == '1'; }();
+        if (!use_v0) return launch_scan_bf16_p8(plan, a, stream);
+        return launch_cfg<2, 4, 8, 4>(plan, a, stream);
+    }
     return launch_cfg<8, 1, 2, 4>(plan, a, stream);
 }
 
