@@ -134,6 +134,7 @@ struct sqe_index {
     DevBuf qb;                     // [b_pad, dim] bf16 queries
     DevBuf cand;                   // [n_chunks, b_pad, CAND_CAP] u64
     DevBuf cand_cnt;               // [n_chunks, b_pad] int
+    DevBuf gmax;                   // [b_pad, ngroups, 64] u32 chunk maxima (global bound table)
 };
 
 struct sqe_cache {
@@ -286,7 +287,7 @@ void sqe_index_destroy(sqe_index* idx) {
         (void)hipStreamSynchronize(idx->ctx->stream);
         if (idx->master) (void)hipFree(idx->master);
         if (idx->scan) (void)hipFree(idx->scan);
-        idx->qn.release(); idx->qb.release(); idx->cand.release(); idx->cand_cnt.release();
+        idx->qn.release(); idx->qb.release(); idx->cand.release(); idx->cand_cnt.release(); idx->gmax.release();
     }
     delete idx;
 }
@@ -410,17 +411,20 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     SQE_TRY(idx->qb.ensure((size_t)plan.b_pad * K * 2));
     SQE_TRY(idx->cand.ensure((size_t)plan.n_chunks * plan.b_pad * CAND_CAP * 8));
     SQE_TRY(idx->cand_cnt.ensure((size_t)plan.n_chunks * plan.b_pad * 4));
+    const size_t gmax_bytes = (size_t)plan.b_pad * plan.ngroups * GMAX_COLS * 4;
+    SQE_TRY(idx->gmax.ensure(gmax_bytes));
     {
         StageTimer t(c->prof, c->stream, ST_PREP);
         if (plan.b_pad > B)
             SQE_HIP(hipMemsetAsync(idx->qb.as<char>() + (size_t)B * K * 2, 0, (size_t)(plan.b_pad - B) * K * 2, c->stream));
         SQE_TRY(launch_normalize_rows(q_dev, B, K, idx->qn.as<float>(), idx->qb.as<bf16_t>(), c->stream));
+        SQE_HIP(hipMemsetAsync(idx->gmax.p, 0, gmax_bytes, c->stream));
     }
     if (idx->n > 0) {
         StageTimer t(c->prof, c->stream, ST_SCAN);
         ScanArgs a;
         a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
-        a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>();
+        a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
         SQE_TRY(launch_scan_bf16(plan, a, c->stream));
     } else {
         SQE_HIP(hipMemsetAsync(idx->cand_cnt.p, 0, (size_t)plan.n_chunks * plan.b_pad * 4, c->stream));

@@ -19,6 +19,7 @@ constexpr int SCAN_BM = 256;        // DB rows per tile
 constexpr int SCAN_BK = 64;         // K elements per pipeline stage
 constexpr int CAND_CAP = 512;       // candidate slots per (chunk, query)
 constexpr int MAX_KP = 256;         // max candidates kept per (chunk, query)
+constexpr int GMAX_COLS = 64;       // chunk maxima per (query, group) row of the global-bound table
 
 struct ScanPlan {
     int bn;               // queries per workgroup tile (256 / 64 / 16)
@@ -28,6 +29,8 @@ struct ScanPlan {
     int n_chunks;         // DB chunks (persistent workgroups per query block)
     int tiles_per_chunk;  // ceil(n_tiles / n_chunks)
     int kp;               // candidates kept per (chunk, query)
+    int ngroups;          // chunk c publishes its maxima to gmax[q][c % ngroups][c / ngroups]
+    int gshift;           // log2 group size of the global bound (64 >> gshift >= kp); -1 = off
 };
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count);
 
@@ -39,6 +42,7 @@ struct ScanArgs {
     int B;
     uint64_t* cand;       // [n_chunks, b_pad, CAND_CAP] candidate keys
     int* cand_cnt;        // [n_chunks, b_pad]
+    uint32_t* gmax;       // [b_pad, ngroups, GMAX_COLS], zeroed before the launch
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless

@@ -3,20 +3,20 @@
 // scores[row, query] = <db[row, :], q[query, :]> over bf16 copies of the L2-normalised
 // vectors, fp32 accumulation on v_mfma_f32_16x16x32_bf16.  The [rows, B] score matrix
 // never reaches HBM: every accumulator is compared in registers against its query's
-// running threshold (the kp-th best key seen so far by this workgroup) and only the
-// rare survivors are appended to a per-(chunk, query) candidate list.
+// running threshold and only the rare survivors are appended to a per-(chunk, query)
+// candidate list (scan_common.h describes the filter).
 //
 // Work decomposition
 //   * the DB is cut into `n_chunks` contiguous runs of 256-row tiles; one PERSISTENT
-//     workgroup owns (chunk, query block) and streams its tiles, so thresholds tighten
-//     as it goes and the expected number of survivors per query is O(kp * log(rows/kp));
+//     workgroup owns (chunk, query block) and streams its tiles;
 //   * blockIdx is remapped so the `qblocks` workgroups that share a chunk sit on ONE XCD
-//     (blocks b and b+8 share an XCD): the DB tile is fetched from HBM once and re-read
-//     from that XCD's L2 by the other query blocks.
+//     (blocks b and b+8 share an XCD): a DB tile fetched by one of them is an L2 hit for
+//     the others while they run in step.
 //
-// Pipeline (per 64-wide K step): both operand tiles go global -> LDS with
-// global_load_lds_dwordx4 (1 KiB per wave-instruction, full 128-B lines), double buffered;
-// the XOR chunk swizzle c' = c ^ ((row >> 1) & 7) is applied on the per-lane SOURCE
+// This file holds the generic two-stage form (one barrier per 64-wide K step, double
+// buffered global_load_lds staging) used for small query blocks; scan8.hip holds the deeper
+// pipeline used for 256-query blocks.  Both operand tiles go global -> LDS in full 128-B
+// lines; the XOR chunk swizzle c' = c ^ ((row >> 1) & 7) is applied on the per-lane SOURCE
 // address and on the ds_read_b128 address (the LDS image itself stays lane-linear), which
 // makes every fragment read bank-conflict free.
 //
@@ -34,8 +34,8 @@ constexpr int THREADS = SCAN_THREADS;
 constexpr int NWAVES = SCAN_NWAVES;
 constexpr int ROW_BYTES = SCAN_ROW_BYTES;
 
-// Issue the global->LDS copy of `rows8 * 8` tile rows x 64 k (128 B per row) spread over
-// the 8 waves.  `gbase` points at (tile_row0, k0); `ld_bytes` is the global row pitch.
+// Issue the global->LDS copy of ROWS tile rows x 64 k (128 B per row) spread over the 8
+// waves.  `gbase` points at (tile_row0, k0); `ld_bytes` is the global row pitch.
 template <int ROWS>
 __device__ __forceinline__ void stage_tile(const char* gbase, size_t ld_bytes, char* lds, int wave, int lane) {
     constexpr int NINSTR = ROWS / 8;          // one 1-KiB wave-instruction per 8 rows
@@ -66,15 +66,15 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     constexpr int BN = WN * FN * 16;
     static_assert(BM == SCAN_BM, "DB tile must be 256 rows");
     static_assert(WM * WN == NWAVES, "8 waves");
+    static_assert(BN % GSLICE_Q == 0, "query block is a whole number of refresh slices");
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int OFF_THR_KEY = 2 * STAGE_BYTES;          // uint64 [BN]
-    constexpr int OFF_THR_S = OFF_THR_KEY + BN * 8;       // float  [BN]
-    constexpr int OFF_CNT = OFF_THR_S + BN * 4;           // int    [BN]
+    constexpr int OFF_F = 2 * STAGE_BYTES;
+    using FL = FilterLds<BN>;
+    constexpr int PER_WAVE = BN / NWAVES;
+    constexpr int NSLICE = BN / GSLICE_Q;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* thr_key = reinterpret_cast<uint64_t*>(smem + OFF_THR_KEY);
-    float* thr_s = reinterpret_cast<float*>(smem + OFF_THR_S);
-    int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
+    char* gstage = smem + OFF_F + FL::OFF_GSTAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,45 +93,75 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 
     const int tile_begin = chunk * p.tiles_per_chunk;
     const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
+    const int nt = tile_end - tile_begin;
     const int KS = p.K / SCAN_BK;
     const size_t ld_bytes = (size_t)p.K * 2;
 
-    // per-query running state
+    Filter f;
+    f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    f.gstride = p.ngroups * GMAX_COLS;
+    const uint32_t* gmax_group = p.gmax + ((size_t)q0 * p.ngroups + (chunk % p.ngroups)) * GMAX_COLS;
+    f.gmax_mine = const_cast<uint32_t*>(gmax_group) + chunk / p.ngroups;
+    f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL::OFF_THR_KEY);
+    f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL::OFF_THR_S);
+    f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL::OFF_CNT);
+    f.cmax = reinterpret_cast<uint32_t*>(smem + OFF_F + FL::OFF_CMAX);
+    f.flags = reinterpret_cast<int*>(smem + OFF_F + FL::OFF_FLAGS);
+    f.n_rows = p.n_rows;
+    f.q_live = min(BN, p.B - q0);
+    f.trig = p.trig;
+    f.per_wave = PER_WAVE;
     for (int i = tid; i < BN; i += THREADS) {
         const bool live = (q0 + i) < p.B;
-        thr_key[i] = live ? 0ull : ~0ull;
-        thr_s[i] = live ? -INFINITY : INFINITY;
-        cnt[i] = 0;
+        f.thr_key[i] = live ? 0ull : ~0ull;
+        f.thr_s[i] = live ? -INFINITY : INFINITY;
+        f.cnt[i] = 0;
+        f.cmax[i] = 0u;
     }
-    uint64_t* cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    if (tid < 16) f.flags[tid] = 0;
 
-    const int total_stages = (tile_end - tile_begin) * KS;
+    // Tile sequence: entry 0 = first tile in BOOT mode, entries 1..nt-1 the other tiles, entry
+    // nt = the first tile again, normally.  (nt == 0: nothing.)
+    const int n_entries = nt > 0 ? nt + 1 : 0;
+    const int total_stages = n_entries * KS;
     const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ld_bytes;
     const char* dbbase = reinterpret_cast<const char*>(p.db);
+    auto tile_of = [&](int e) { return e < nt ? tile_begin + e : tile_begin; };
 
     f32x4 acc[FM][FN];
 
     if (total_stages > 0) {
-        // prologue: stage 0
         stage_tile<BM>(dbbase + (size_t)tile_begin * BM * ld_bytes, ld_bytes, smem, wave, lane);
         stage_tile<BN>(qbase, ld_bytes, smem + BM * ROW_BYTES, wave, lane);
     }
     __syncthreads();   // vmcnt(0) + barrier: stage 0 landed, state initialised
 
-    int tile = tile_begin;
+    int entry = 0;
     int ks = 0;
+    int refresh_pending = -1;      // slice fetched during the previous K step
+    int refresh_ctr = 0;
     for (int s = 0; s < total_stages; ++s) {
         char* cur = smem + (s & 1) * STAGE_BYTES;
+        // the bound rows fetched during the previous K step have landed (barrier below)
+        if (refresh_pending >= 0) {
+            refresh_apply(f, gstage, refresh_pending, p.gshift, wave, lane);
+            refresh_pending = -1;
+        }
         // prefetch the next stage into the other buffer (its readers finished before the
         // barrier that ended the previous iteration)
         if (s + 1 < total_stages) {
-            int ntile = tile, nks = ks + 1;
-            if (nks == KS) { nks = 0; ++ntile; }
+            int nentry = entry, nks = ks + 1;
+            if (nks == KS) { nks = 0; ++nentry; }
             char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
-            stage_tile<BM>(dbbase + (size_t)ntile * BM * ld_bytes + (size_t)nks * ROW_BYTES, ld_bytes, nxt, wave, lane);
+            stage_tile<BM>(dbbase + (size_t)tile_of(nentry) * BM * ld_bytes + (size_t)nks * ROW_BYTES, ld_bytes, nxt, wave, lane);
             stage_tile<BN>(qbase + (size_t)nks * ROW_BYTES, ld_bytes, nxt + BM * ROW_BYTES, wave, lane);
         }
         if (ks == 0) {
+            if (entry > 0 && p.gshift >= 0) {       // one slice of the global bound per tile
+                refresh_pending = refresh_ctr % NSLICE;
+                ++refresh_ctr;
+                refresh_issue(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -155,69 +185,37 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         }
 
         if (ks == KS - 1) {
-            // ---------------- fused top-k filter on the finished 256 x BN tile
-            float thr[FN];
-            bool hit = false;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                thr[j] = thr_s[wn * (FN * 16) + j * 16 + (lane & 15)];
-                float mx = acc[0][j][0];
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
-                hit |= (mx >= thr[j]);
-            }
-            if (__any(hit)) {
-                const int64_t row_base = (int64_t)tile * BM + wm * (FM * 16) + (lane >> 4) * 4;
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int qcol = wn * (FN * 16) + j * 16 + (lane & 15);
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float sc = acc[i][j][r];
-                            if (sc >= thr[j]) {
-                                const int64_t row = row_base + i * 16 + r;
-                                if (row < p.n_rows && (q0 + qcol) < p.B) {
-                                    const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
-                                    if (key > thr_key[qcol]) {
-                                        const int slot = atomicAdd(&cnt[qcol], 1);
-                                        cand_base[(size_t)qcol * CAND_CAP + slot] = key;
-                                    }
-                                }
-                            }
-                        }
-                    }
+            const int64_t row0 = (int64_t)tile_of(entry) * BM;
+            if (entry == 0) {
+                filter_boot<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
+                __syncthreads();
+                publish_cmax(f, wave * PER_WAVE, PER_WAVE, lane);
+            } else {
+                filter_tile<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
+                __syncthreads();   // appends of this tile visible workgroup-wide
+                if (__builtin_amdgcn_readfirstlane(f.flags[wave]) != 0) {
+                    if (lane == 0) f.flags[wave] = 0;
+                    compact_owned(f, wave * PER_WAVE, PER_WAVE, p.trig, p.kp, lane);
                 }
             }
-            __syncthreads();   // appends of this tile visible workgroup-wide
-            // lists that could overflow on the next tile are cut back to their best kp
-            compact_owned(cand_base, wave * (BN / NWAVES), BN / NWAVES, p.trig, p.kp, lane, cnt, thr_s, thr_key);
         }
         ++ks;
-        if (ks == KS) { ks = 0; ++tile; }
+        if (ks == KS) { ks = 0; ++entry; }
         __syncthreads();   // next stage landed (vmcnt(0)); everyone done with `cur`; state settled
     }
 
     // final: every list down to <= kp entries, counts published
-    compact_owned(cand_base, wave * (BN / NWAVES), BN / NWAVES, p.kp + 1, p.kp, lane, cnt, thr_s, thr_key);
+    compact_owned(f, wave * PER_WAVE, PER_WAVE, p.kp + 1, p.kp, lane);
     __syncthreads();
     for (int i = tid; i < BN; i += THREADS)
-        p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
+        p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
 }
 
 template <int WM, int WN, int FM, int FN>
 int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     constexpr int BN = WN * FN * 16;
-    constexpr int LDS = 2 * (SCAN_BM + BN) * ROW_BYTES + BN * 16;
-    ScanKernelArgs k;
-    k.db = a.db; k.q = a.q; k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = plan.b_pad;
-    k.n_tiles = plan.n_tiles; k.tiles_per_chunk = plan.tiles_per_chunk; k.n_chunks = plan.n_chunks;
-    k.qblocks = plan.qblocks; k.kp = plan.kp;
-    k.trig = plan.kp > 128 ? plan.kp : 128;
-    k.cand = a.cand; k.cand_cnt = a.cand_cnt;
+    constexpr int LDS = 2 * (SCAN_BM + BN) * ROW_BYTES + FilterLds<BN>::BYTES;
+    ScanKernelArgs k = make_kernel_args(plan, a);
     auto kern = scan_bf16_kernel<WM, WN, FM, FN>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -232,6 +230,17 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
+    ScanKernelArgs k;
+    k.db = a.db; k.q = a.q; k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = plan.b_pad;
+    k.n_tiles = plan.n_tiles; k.tiles_per_chunk = plan.tiles_per_chunk; k.n_chunks = plan.n_chunks;
+    k.qblocks = plan.qblocks; k.kp = plan.kp;
+    k.trig = plan.kp > 128 ? plan.kp : 128;
+    k.ngroups = plan.ngroups; k.gshift = plan.gshift;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax;
+    return k;
+}
+
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     ScanPlan p;
     p.bn = B > 64 ? 256 : 64;
@@ -240,11 +249,15 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     p.n_tiles = (int)((n_rows + SCAN_BM - 1) / SCAN_BM);
     int chunks = cu_count / p.qblocks;                 // one persistent workgroup per CU
     if (chunks < 1) chunks = 1;
-    // keep n_chunks * qblocks a multiple of 8 when possible so the XCD remap applies
+    // a multiple of 64 chunks fills the 64 columns of the global-bound table
+    if (chunks >= GMAX_COLS) chunks = chunks / GMAX_COLS * GMAX_COLS;
     if (chunks > p.n_tiles) chunks = p.n_tiles > 0 ? p.n_tiles : 1;
     p.tiles_per_chunk = p.n_tiles > 0 ? (p.n_tiles + chunks - 1) / chunks : 0;
     p.n_chunks = p.tiles_per_chunk > 0 ? (p.n_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk : 1;
     p.kp = kp;
+    p.ngroups = (p.n_chunks + GMAX_COLS - 1) / GMAX_COLS;
+    // global bound: 64 >> gshift groups, each contributing one distinct row, must be >= kp
+    p.gshift = kp <= 16 ? 2 : kp <= 32 ? 1 : kp <= 64 ? 0 : -1;
     return p;
 }
 

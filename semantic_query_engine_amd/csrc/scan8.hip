@@ -22,10 +22,12 @@
 //     barrier: while one group issues LDS reads + DMA and waits, the other group's MFMA
 //     cluster owns the matrix pipe.
 //
-// The filter epilogue of tile T runs at the top of tile T+1's first phase (its VALU work
-// overlaps the other group's MFMAs); list compaction for tile T runs two phases later, when
-// both groups' appends are published (each appending wave drains its stores before its
-// next barrier).
+// Filter placement: the filter of tile entry e runs at the top of entry e+1's first phase (its
+// VALU work overlaps the other group's MFMAs); what needs every wave's contribution (publishing
+// the boot maxima, list compaction) runs two phases later, when both groups' filter stores are
+// published (each storing wave drains its stores before its next barrier).  The global-bound
+// rows are fetched by LDS-DMA in phase 0 of an entry's first K step (older than the six
+// youngest DMA pieces at the phase-3 wait, hence retired by it) and folded one K step later.
 #include "scan_common.h"
 
 namespace sqe {
@@ -35,11 +37,10 @@ namespace {
 constexpr int UNIT_BYTES = 128 * SCAN_ROW_BYTES;     // 16 KiB
 constexpr int NSLOTS = 8;
 constexpr int BN8 = 256;
-constexpr int OFF_THR_KEY = NSLOTS * UNIT_BYTES;     // uint64 [256]
-constexpr int OFF_THR_S = OFF_THR_KEY + BN8 * 8;     // float  [256]
-constexpr int OFF_CNT = OFF_THR_S + BN8 * 4;         // int    [256]
-constexpr int OFF_FLAGS = OFF_CNT + BN8 * 4;        // int    [8]: wave w must sweep its lists
-constexpr int LDS_BYTES = OFF_FLAGS + 64;
+constexpr int OFF_F = NSLOTS * UNIT_BYTES;
+using FL8 = FilterLds<BN8>;
+constexpr int LDS_BYTES = OFF_F + FL8::BYTES;
+constexpr int NSLICE8 = BN8 / GSLICE_Q;
 
 #define SQE_BARRIER()                          \
     do {                                       \
@@ -63,66 +64,9 @@ __device__ __forceinline__ bf16x8 unit_frag(const char* slot, int ru, int c) {
     return *reinterpret_cast<const bf16x8*>(slot + ru * SCAN_ROW_BYTES + ((c ^ ((ru >> 1) & 7)) << 4));
 }
 
-struct Filter {
-    uint64_t* cand_base;   // this workgroup's lists: [256][CAND_CAP]
-    uint64_t* thr_key;
-    float* thr_s;
-    int* cnt;
-    int* flags;            // [8] per owner wave: some owned list reached the compaction trigger
-    int64_t n_rows;
-    int q_live;            // number of live queries in this block (B - q0, clamped to 256)
-    int trig;
-};
-
-// Compare the finished tile against the per-query thresholds; append survivors.
-// Returns true when this wave stored candidates (caller must drain its stores).
-__device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[8][4], const Filter& f, int64_t tile_row0,
-                                            int wm, int wn, int lane) {
-    float thr[4];
-    bool hit = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        thr[j] = f.thr_s[wn * 64 + j * 16 + (lane & 15)];
-        float mx = acc[0][j][0];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
-        hit |= (mx >= thr[j]);
-    }
-    if (!__any(hit)) return false;
-    const int64_t row_base = tile_row0 + wm * 128 + (lane >> 4) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int qcol = wn * 64 + j * 16 + (lane & 15);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sc = acc[i][j][r];
-                if (sc >= thr[j]) {
-                    const int64_t row = row_base + i * 16 + r;
-                    if (row < f.n_rows && qcol < f.q_live) {
-                        const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
-                        if (key > f.thr_key[qcol]) {
-                            const int slot = atomicAdd(&f.cnt[qcol], 1);
-                            f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;
-                            if (slot + 1 >= f.trig) f.flags[qcol >> 5] = 1;   // owner wave = qcol / 32
-                        }
-                    }
-                }
-            }
-        }
-    }
-    return true;
-}
-
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* thr_key = reinterpret_cast<uint64_t*>(smem + OFF_THR_KEY);
-    float* thr_s = reinterpret_cast<float*>(smem + OFF_THR_S);
-    int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
-    int* flags = reinterpret_cast<int*>(smem + OFF_FLAGS);
+    char* gstage = smem + OFF_F + FL8::OFF_GSTAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,23 +83,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
 
     const int tile_begin = chunk * p.tiles_per_chunk;
     const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
+    const int nt = tile_end - tile_begin;
     const int KS = p.K / SCAN_BK;
-    const int S = (tile_end - tile_begin) * KS;      // K steps of this workgroup
+    // entries: 0 = first tile (BOOT), 1..nt-1 = the other tiles, nt = the first tile again
+    const int n_entries = nt > 0 ? nt + 1 : 0;
+    const int S = n_entries * KS;                    // K steps of this workgroup
     const size_t ld = (size_t)p.K * 2;
+    auto tile_of = [&](int e) { return e < nt ? tile_begin + e : tile_begin; };
 
+    Filter f;
+    f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    f.gstride = p.ngroups * GMAX_COLS;
+    const uint32_t* gmax_group = p.gmax + ((size_t)q0 * p.ngroups + (chunk % p.ngroups)) * GMAX_COLS;
+    f.gmax_mine = const_cast<uint32_t*>(gmax_group) + chunk / p.ngroups;
+    f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL8::OFF_THR_KEY);
+    f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL8::OFF_THR_S);
+    f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL8::OFF_CNT);
+    f.cmax = reinterpret_cast<uint32_t*>(smem + OFF_F + FL8::OFF_CMAX);
+    f.flags = reinterpret_cast<int*>(smem + OFF_F + FL8::OFF_FLAGS);
+    f.n_rows = p.n_rows;
+    f.q_live = min(BN8, p.B - q0);
+    f.trig = p.trig;
+    f.per_wave = 32;
     for (int i = tid; i < BN8; i += SCAN_THREADS) {
         const bool live = (q0 + i) < p.B;
-        thr_key[i] = live ? 0ull : ~0ull;
-        thr_s[i] = live ? -INFINITY : INFINITY;
-        cnt[i] = 0;
+        f.thr_key[i] = live ? 0ull : ~0ull;
+        f.thr_s[i] = live ? -INFINITY : INFINITY;
+        f.cnt[i] = 0;
+        f.cmax[i] = 0u;
     }
-    if (tid < 8) flags[tid] = 0;
-    Filter flt;
-    flt.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
-    flt.thr_key = thr_key; flt.thr_s = thr_s; flt.cnt = cnt; flt.flags = flags;
-    flt.trig = p.trig;
-    flt.n_rows = p.n_rows;
-    flt.q_live = min(BN8, p.B - q0);
+    if (tid < 16) f.flags[tid] = 0;
 
     // ---- per-lane source offsets of this wave's two DMA pieces per unit (h = 0 form)
     int offA[2], offB[2];
@@ -171,7 +128,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
 
     const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ld;
     const char* dbbase = reinterpret_cast<const char*>(p.db);
-    auto a_src = [&](int tile, int ks) { return dbbase + (size_t)tile * SCAN_BM * ld + (size_t)ks * SCAN_ROW_BYTES; };
+    auto a_src = [&](int e, int ks) { return dbbase + (size_t)tile_of(e) * SCAN_BM * ld + (size_t)ks * SCAN_ROW_BYTES; };
     auto b_src = [&](int ks) { return qbase + (size_t)ks * SCAN_ROW_BYTES; };
     auto slot_of = [&](int s, int u) { return smem + (((s & 1) << 2) + u) * UNIT_BYTES; };
 
@@ -183,41 +140,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     f32x4 acc[8][4];
     bf16x8 a[4][2], b[2][2];
 
+    // (entry, ks) of K steps s, s+1, s+2
+    int e0 = 0, ks0 = 0;
+    int e1 = 0, ks1 = 1;
+    if (ks1 == KS) { ks1 = 0; ++e1; }
+    int e2 = e1, ks2 = ks1 + 1;
+    if (ks2 == KS) { ks2 = 0; ++e2; }
+
     // ---- prologue: K step 0 (all four units) and K step 1 (u0..u2)
     if (S > 0) {
-        const char* a0 = a_src(tile_begin, 0);
+        const char* a0 = a_src(0, 0);
         const char* b0 = b_src(0);
         issue_unit(a0, offA[0], offA[1], slot_of(0, 0), wave);
         issue_unit(b0 + b1_off, offB[0], offB[1], slot_of(0, 1), wave);
         issue_unit(a0 + a1_off, offA[0], offA[1], slot_of(0, 2), wave);
         issue_unit(b0, offB[0], offB[1], slot_of(0, 3), wave);
-        if (S > 1) {
-            const int t1 = KS > 1 ? tile_begin : tile_begin + 1;
-            const int k1 = KS > 1 ? 1 : 0;
-            const char* a1 = a_src(t1, k1);
-            const char* b1p = b_src(k1);
-            issue_unit(a1, offA[0], offA[1], slot_of(1, 0), wave);
-            issue_unit(b1p + b1_off, offB[0], offB[1], slot_of(1, 1), wave);
-            issue_unit(a1 + a1_off, offA[0], offA[1], slot_of(1, 2), wave);
-        }
+        const char* a1 = a_src(e1, ks1);      // S >= 2 whenever S > 0 (boot + rescan entries)
+        const char* b1p = b_src(ks1);
+        issue_unit(a1, offA[0], offA[1], slot_of(1, 0), wave);
+        issue_unit(b1p + b1_off, offB[0], offB[1], slot_of(1, 1), wave);
+        issue_unit(a1 + a1_off, offA[0], offA[1], slot_of(1, 2), wave);
     }
     __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
     if (wm == 1) SQE_BARRIER();            // stagger: group 1 runs one barrier behind group 0
 
-    // (tile, ks) of K steps s, s+1, s+2
-    int tile = tile_begin, ks = 0;
-    int tile1 = tile_begin, ks1 = 1;
-    if (ks1 == KS) { ks1 = 0; ++tile1; }
-    int tile2 = tile1, ks2 = ks1 + 1;
-    if (ks2 == KS) { ks2 = 0; ++tile2; }
-
+    int refresh_pending = -1;
+    int refresh_ctr = 0;
     for (int s = 0; s < S; ++s) {
         const char* u0 = slot_of(s, 0);
         const char* u1 = slot_of(s, 1);
         const char* u2 = slot_of(s, 2);
         const char* u3 = slot_of(s, 3);
+        const bool entry_start = ks0 == 0 && s > 0;
 
-        // ================= phase 0: quadrant (A^0, B^0); frees nothing new, loads (s+1, u3)
+        // ================= phase 0: quadrant (A^0, B^0); loads (s+1, u3)
 #pragma unroll
         for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
@@ -226,12 +182,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
         for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) a[fm][kk] = unit_frag(u0, ruA + fm * 16, kk * 4 + cq);
+        if (refresh_pending >= 0) {          // fetched during the previous K step, retired by its phase-3 wait
+            refresh_apply(f, gstage, refresh_pending, p.gshift, wave, lane);
+            refresh_pending = -1;
+        }
+        if (entry_start && p.gshift >= 0) {  // one slice of the global bound per tile entry
+            refresh_pending = refresh_ctr % NSLICE8;
+            ++refresh_ctr;
+            refresh_issue(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
+        }
         if (s + 1 < S) issue_unit(b_src(ks1), offB[0], offB[1], const_cast<char*>(slot_of(s + 1, 3)), wave);
-        if (ks == 0) {
+        if (ks0 == 0) {
             if (s > 0) {
-                // filter of the tile finished by the previous K step
-                if (filter_tile(acc, flt, (int64_t)(tile - 1) * SCAN_BM, wm, wn, lane))
+                // filter of the entry finished by the previous K step
+                const int64_t row0 = (int64_t)tile_of(e0 - 1) * SCAN_BM;
+                if (e0 - 1 == 0) {
+                    filter_boot<8, 4>(acc, f, row0, wm * 128, wn * 64, lane);
+                } else if (filter_tile<8, 4>(acc, f, row0, wm * 128, wn * 64, lane)) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // publish appended keys
+                }
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -254,7 +223,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
         for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) b[fn][kk] = unit_frag(u1, ruB + fn * 16, kk * 4 + cq);
-        if (s + 2 < S) issue_unit(a_src(tile2, ks2), offA[0], offA[1], const_cast<char*>(u0), wave);
+        if (s + 2 < S) issue_unit(a_src(e2, ks2), offA[0], offA[1], const_cast<char*>(u0), wave);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SQE_BARRIER();
 #pragma unroll
@@ -267,13 +236,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
         SQE_BARRIER();
 
         // ================= phase 2: quadrant (A^1, B^1); u1 is dead -> (s+2, u1)
-        if (ks == 0 && s > 0) {
-            // both groups' appends for the previous tile are published by now.  The flag word has
-            // a wave-uniform address, so the common "nothing to do" check keeps no per-lane
-            // address register alive across the loop (a spilled one would drain the DMA queue).
-            if (__builtin_amdgcn_readfirstlane(flags[wave]) != 0) {
-                if (lane == 0) flags[wave] = 0;
-                compact_owned(flt.cand_base, wave * 32, 32, p.trig, p.kp, lane, cnt, thr_s, thr_key);
+        if (entry_start) {
+            // both groups' filter stores for the previous entry are published by now.  Done before
+            // the A^1 fragment reads so the sweep's registers do not stack on top of them; the flag
+            // word has a wave-uniform address (no per-lane address kept alive across the loop).
+            if (e0 - 1 == 0) {
+                publish_cmax(f, wave * 32, 32, lane);
+            } else if (__builtin_amdgcn_readfirstlane(f.flags[wave]) != 0) {
+                if (lane == 0) f.flags[wave] = 0;
+                compact_owned(f, wave * 32, 32, p.trig, p.kp, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -299,7 +270,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) b[fn][kk] = unit_frag(u3, ruB + fn * 16, kk * 4 + cq);
         if (s + 2 < S) {
-            issue_unit(a_src(tile2, ks2) + a1_off, offA[0], offA[1], const_cast<char*>(u2), wave);
+            issue_unit(a_src(e2, ks2) + a1_off, offA[0], offA[1], const_cast<char*>(u2), wave);
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -314,35 +285,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
                     acc[4 + fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[4 + fm][fn], 0, 0, 0);
         SQE_BARRIER();
 
-        // advance (tile, ks) windows
-        tile = tile1; ks = ks1;
-        tile1 = tile2; ks1 = ks2;
-        if (++ks2 == KS) { ks2 = 0; ++tile2; }
+        // advance the (entry, ks) windows
+        e0 = e1; ks0 = ks1;
+        e1 = e2; ks1 = ks2;
+        if (++ks2 == KS) { ks2 = 0; ++e2; }
     }
 
-    // ---- tail: filter of the last tile, re-align the groups, final compaction
+    // ---- tail: filter of the last entry (the rescan of the first tile, or nothing)
     if (S > 0) {
-        if (filter_tile(acc, flt, (int64_t)(tile_end - 1) * SCAN_BM, wm, wn, lane))
+        if (filter_tile<8, 4>(acc, f, (int64_t)tile_begin * SCAN_BM, wm * 128, wn * 64, lane))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (wm == 0) SQE_BARRIER();            // undo the stagger
     __syncthreads();
-    compact_owned(flt.cand_base, wave * 32, 32, p.kp + 1, p.kp, lane, cnt, thr_s, thr_key);
+    compact_owned(f, wave * 32, 32, p.kp + 1, p.kp, lane);
     __syncthreads();
     for (int i = tid; i < BN8; i += SCAN_THREADS)
-        p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
+        p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
 }
 
 }  // namespace
 
 int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (plan.bn != BN8) return fail(SQE_ERR_INVALID, "scan p8: query block must be 256");
-    ScanKernelArgs k;
-    k.db = a.db; k.q = a.q; k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = plan.b_pad;
-    k.n_tiles = plan.n_tiles; k.tiles_per_chunk = plan.tiles_per_chunk; k.n_chunks = plan.n_chunks;
-    k.qblocks = plan.qblocks; k.kp = plan.kp;
-    k.trig = plan.kp > 128 ? plan.kp : 128;
-    k.cand = a.cand; k.cand_cnt = a.cand_cnt;
+    ScanKernelArgs k = make_kernel_args(plan, a);
     static bool attr_set = false;
     if (!attr_set) {
         SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bf16_p8_kernel),

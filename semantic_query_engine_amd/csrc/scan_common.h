@@ -1,5 +1,22 @@
-// scan_common.h -- device code shared by the scan kernels: kernel argument block, the
-// candidate-list machinery (threshold filter, append, wave-level compaction).
+// scan_common.h -- device code shared by the scan kernels: kernel argument block and the
+// fused top-k filter (thresholds, candidate lists, cross-chunk bound, compaction).
+//
+// Filter design
+//   * Every persistent workgroup (chunk c, query block) keeps per query: a threshold key
+//     (LDS), a candidate list (global, CAND_CAP slots) and the best score it has seen.
+//   * A row survives when its key exceeds the threshold.  The threshold is the maximum of
+//       - the LOCAL bound: the kp-th best key of this chunk so far (set by list compaction);
+//       - the GLOBAL bound: every chunk publishes its per-query maximum score to a small
+//         table gmax[query][group][64]; for 64 published maxima m_0..m_63 (64 distinct real
+//         rows) min over g-sized groups of max-in-group is a score that at least 64/g >= kp
+//         distinct rows reach, hence a lower bound of the final kp-th best score.  With all
+//         chunks streaming in parallel this bound tracks the whole index, not one chunk, so
+//         survivors become rare after the first few tiles.
+//   * The first tile of a chunk runs in BOOT mode: it only folds per-lane maxima into the
+//     chunk maximum (no appends, so no first-tile append storm); that tile is scanned again,
+//     normally, at the end of the chunk.
+//   * The gmax rows a workgroup needs are fetched with global_load_lds (no VGPR loads in the
+//     pipelined loops: a VGPR load would make hipcc drain the DMA queue).
 #pragma once
 
 #include "kernels.h"
@@ -9,6 +26,8 @@ namespace sqe {
 constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_NWAVES = 8;
 constexpr int SCAN_ROW_BYTES = SCAN_BK * 2;   // 128 B per tile row per 64-wide bf16 K step
+constexpr int GSLICE_Q = 64;                  // queries refreshed per gmax fetch
+constexpr int GSTAGE_BYTES = GSLICE_Q * GMAX_COLS * 4;   // 16 KiB
 
 struct ScanKernelArgs {
     const bf16_t* db;
@@ -23,10 +42,48 @@ struct ScanKernelArgs {
     int qblocks;
     int kp;
     int trig;            // compaction trigger (kp <= trig <= CAND_CAP - SCAN_BM)
+    int ngroups;         // chunk c publishes to gmax[q][c % ngroups][c / ngroups]
+    int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
     uint64_t* cand;
     int* cand_cnt;
+    uint32_t* gmax;      // [b_pad][ngroups][GMAX_COLS] orderable scores, 0 = nothing yet
 };
 
+// LDS block of the filter state for a query block of BN queries (after the staging area).
+template <int BN>
+struct FilterLds {
+    static constexpr int OFF_THR_KEY = 0;                       // uint64 [BN]
+    static constexpr int OFF_THR_S = OFF_THR_KEY + BN * 8;      // float  [BN]
+    static constexpr int OFF_CNT = OFF_THR_S + BN * 4;          // int    [BN]
+    static constexpr int OFF_CMAX = OFF_CNT + BN * 4;           // uint32 [BN] chunk max (orderable)
+    static constexpr int OFF_FLAGS = OFF_CMAX + BN * 4;         // int    [16]
+    static constexpr int OFF_GSTAGE = OFF_FLAGS + 64;           // uint32 [GSLICE_Q][GMAX_COLS]
+    static constexpr int BYTES = OFF_GSTAGE + GSTAGE_BYTES;
+};
+
+struct Filter {
+    uint64_t* cand_base;   // this workgroup's lists: [BN][CAND_CAP]
+    uint32_t* gmax_mine;   // &gmax[q0][group][col]: this chunk's column, query stride = ngroups*64
+    uint64_t* thr_key;
+    float* thr_s;
+    int* cnt;
+    uint32_t* cmax;
+    int* flags;            // [8] per owner wave: an owned list reached the compaction trigger
+    int64_t n_rows;
+    int q_live;            // live queries in this block
+    int trig;
+    int per_wave;          // queries owned per wave (BN / 8)
+    int gstride;           // ngroups * GMAX_COLS (uint32 elements between consecutive queries)
+};
+
+// host: kernel argument block from a plan (scan.hip)
+ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a);
+
+__device__ __forceinline__ void store_sc1_u32(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------- compaction
 // kth largest of the (unique, non-zero) keys held as k[j] by the wave; zero = empty slot.
 template <int NREG>
 __device__ __forceinline__ uint64_t wave_select_kth(const uint64_t (&k)[NREG], int nreg, int kth) {
@@ -44,9 +101,8 @@ __device__ __forceinline__ uint64_t wave_select_kth(const uint64_t (&k)[NREG], i
     return prefix;
 }
 
-// Wave-level compaction of one candidate list to its best `kp` keys; updates the
-// threshold of that query.  Caller guarantees n > kp and that no other wave touches
-// this list concurrently.
+// Wave-level compaction of one candidate list to its best `kp` keys; raises the threshold of
+// that query to the kp-th best.  Caller guarantees n > kp and exclusive access to the list.
 __device__ __forceinline__ void compact_list(uint64_t* list, int n, int kp, int lane,
                                              int* cnt_slot, float* thr_s_slot, uint64_t* thr_key_slot) {
     constexpr int NREG = CAND_CAP / 64;
@@ -70,22 +126,147 @@ __device__ __forceinline__ void compact_list(uint64_t* list, int n, int kp, int 
     }
     if (lane == 0) {
         *cnt_slot = base;                // == kp
-        *thr_key_slot = T;
-        *thr_s_slot = key_score(T);
+        if (T > *thr_key_slot) {
+            *thr_key_slot = T;
+            *thr_s_slot = key_score(T);
+        }
     }
 }
 
-// Compaction sweep over the `per_wave` queries a wave owns: any list at or above `limit`
-// entries is cut back to its best kp.  Must be called wave-uniformly.
-__device__ __forceinline__ void compact_owned(uint64_t* cand_base, int first_q, int per_wave, int limit,
-                                              int kp, int lane, int* cnt, float* thr_s, uint64_t* thr_key) {
+// Sweep over the `per_wave` queries a wave owns: any list with at least `limit` entries is
+// cut back to its best kp.  Wave-uniform call.
+__device__ __forceinline__ void compact_owned(const Filter& f, int first_q, int per_wave, int limit,
+                                              int kp, int lane) {
     const int myq = first_q + lane;
-    const bool need = lane < per_wave && cnt[myq] >= limit;
+    const bool need = lane < per_wave && f.cnt[myq] >= limit;
     uint64_t mask = __ballot(need);
     while (mask) {
         const int bq = first_q + (int)__builtin_ctzll(mask);
         mask &= mask - 1;
-        compact_list(cand_base + (size_t)bq * CAND_CAP, cnt[bq], kp, lane, &cnt[bq], &thr_s[bq], &thr_key[bq]);
+        compact_list(f.cand_base + (size_t)bq * CAND_CAP, f.cnt[bq], kp, lane, &f.cnt[bq], &f.thr_s[bq],
+                     &f.thr_key[bq]);
+    }
+}
+
+// ---------------------------------------------------------------- per-tile filter
+// Accumulator layout of a wave: acc[i][j][r] = score(tile row  row0 + i*16 + (lane>>4)*4 + r,
+//                                               query col col0 + j*16 + (lane&15)).
+
+// BOOT mode: fold the tile's per-lane maxima into the chunk maxima (no appends).
+template <int FM, int FN>
+__device__ __forceinline__ void filter_boot(const f32x4 (&acc)[FM][FN], const Filter& f, int64_t tile_row0,
+                                            int row0, int col0, int lane) {
+    const bool partial = tile_row0 + SCAN_BM > f.n_rows;     // only the last tile of the index
+    const int64_t row_base = tile_row0 + row0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r];
+                if (partial && row_base + i * 16 + r >= f.n_rows) v = -INFINITY;
+                mx = fmaxf(mx, v);
+            }
+        const int qcol = col0 + j * 16 + (lane & 15);
+        if (mx > -INFINITY) atomicMax(&f.cmax[qcol], f32_orderable(mx + 0.0f));
+    }
+}
+
+// Publish the chunk maxima of the queries a wave owns (after every wave's filter_boot).
+__device__ __forceinline__ void publish_cmax(const Filter& f, int first_q, int per_wave, int lane) {
+    if (lane < per_wave && first_q + lane < f.q_live) {
+        const uint32_t m = f.cmax[first_q + lane];
+        if (m) store_sc1_u32(f.gmax_mine + (size_t)(first_q + lane) * f.gstride, m);
+    }
+}
+
+// Normal mode.  Returns true when this wave stored candidates (the caller drains its stores
+// before the next barrier so other waves can read the lists).
+template <int FM, int FN>
+__device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Filter& f, int64_t tile_row0,
+                                            int row0, int col0, int lane) {
+    bool stored = false;
+    const int64_t row_base = tile_row0 + row0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int qcol = col0 + j * 16 + (lane & 15);
+        const float thr = f.thr_s[qcol];
+        float fmx[FM];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            fmx[i] = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
+            mx = fmaxf(mx, fmx[i]);
+        }
+        if (__any(mx >= thr)) {                     // rare: some lane of this column group has a survivor
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if (__any(fmx[i] >= thr)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = acc[i][j][r];
+                        if (sc >= thr) {
+                            const int64_t row = row_base + i * 16 + r;
+                            if (row < f.n_rows && qcol < f.q_live) {
+                                const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
+                                if (key > f.thr_key[qcol]) {
+                                    const int slot = atomicAdd(&f.cnt[qcol], 1);
+                                    f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;
+                                    if (slot + 1 >= f.trig) f.flags[qcol / f.per_wave] = 1;
+                                    const uint32_t o = (uint32_t)(key >> 32);
+                                    if (o > atomicMax(&f.cmax[qcol], o))
+                                        store_sc1_u32(f.gmax_mine + (size_t)qcol * f.gstride, o);
+                                    stored = true;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return __any(stored);
+}
+
+// ---------------------------------------------------------------- global bound refresh
+// Issue the LDS-DMA fetch of the gmax rows of GSLICE_Q queries (slice `sl` of the block):
+// 16 pieces of 1 KiB (4 query rows of 256 B each), wave w issues pieces w and w + 8.
+__device__ __forceinline__ void refresh_issue(const uint32_t* gmax_block_group, int gstride, int sl,
+                                              char* gstage, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int piece = wave + 8 * t;
+        const int qq = piece * 4 + (lane >> 4);                      // query within the slice
+        const char* src = reinterpret_cast<const char*>(gmax_block_group + (size_t)(sl * GSLICE_Q + qq) * gstride) +
+                          (lane & 15) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(gstage + piece * 1024),
+                                         16, 0, /*aux: sc1*/ 16);
+    }
+}
+
+// After the fetch has landed: wave w folds queries w*8 .. w*8+7 of the slice.
+__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift,
+                                              int wave, int lane) {
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(gstage);
+#pragma unroll
+    for (int t = 0; t < GSLICE_Q / SCAN_NWAVES; ++t) {
+        const int qq = wave * (GSLICE_Q / SCAN_NWAVES) + t;
+        uint32_t v = st[qq * GMAX_COLS + lane];
+        // max inside groups of 2^gshift neighbouring lanes, then min over all lanes
+        for (int d = 1; d < (1 << gshift); d <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+        const int q = sl * GSLICE_Q + qq;
+        if (lane == 0 && v != 0u && q < f.q_live) {
+            const uint64_t gk = (uint64_t)v << 32;
+            if (gk > f.thr_key[q]) {
+                f.thr_key[q] = gk;
+                f.thr_s[q] = f32_from_orderable(v);
+            }
+        }
     }
 }
 
