@@ -66,6 +66,15 @@ __device__ __forceinline__ uint64_t make_key(float score, uint32_t row) {
 __device__ __forceinline__ uint32_t key_row(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)key; }
 __device__ __forceinline__ float key_score(uint64_t key) { return f32_from_orderable((uint32_t)(key >> 32)); }
 
+// Lane id recomputed on the spot (2 VALU ops).  Used in rarely-run blocks of the pipelined
+// kernels so that no per-lane address has to stay alive across the main loop: a spilled one
+// is reloaded with a scratch load, whose compiler-inserted vmcnt(0) drains the DMA queue.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

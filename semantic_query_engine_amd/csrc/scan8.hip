@@ -1,33 +1,37 @@
 // scan8.hip -- S2, pipelined form of the bf16 scan for query blocks of 256 (gfx950).
 //
 // Same contract as scan.hip (256-row DB tile x 256 queries per persistent workgroup, fused
-// top-k filter, candidate lists) with a deeper software pipeline:
+// top-k filter, candidate lists) with a software pipeline at two levels:
 //
-//   * every 64-wide K step is split into four 16-KiB UNITS
-//         u0 = A^0  rows    {wm*128 +      0..63}   (wm = 0,1)      read in phase 0
-//         u1 = B^1  queries {wn*64  + 32 + 0..31}   (wn = 0..3)     read in phase 1
-//         u2 = A^1  rows    {wm*128 + 64 + 0..63}                   read in phase 2
-//         u3 = B^0  queries {wn*64  +      0..31}                   read in phases 0 and 3
-//     so each unit has ONE last reader phase; 8 unit slots of LDS (128 KiB) form a ring
-//     (slot = 4 * (kstep & 1) + u);
-//   * phase p of K step s computes one 64x32 quadrant of every wave's 128x64 output
-//     (16 x v_mfma_f32_16x16x32_bf16) and issues the global_load_lds of ONE unit, 7 units
-//     ahead of the unit it frees:  p0 -> (s+1,u3), p1 -> (s+2,u0), p2 -> (s+2,u1),
-//     p3 -> (s+2,u2).  A unit is overwritten one phase after its last reader phase, whose
-//     reads were retired (lgkmcnt(0)) before that phase's first barrier;
-//   * ONE counted wait per K step: s_waitcnt vmcnt(6) in phase 3 leaves the three youngest
-//     units in flight and retires everything K step s+1 needs; it sits before the phase's
-//     first barrier, so after the second barrier every wave's portion has landed;
-//   * the two wave rows (wm = 0 / 1, one wave of each per SIMD) run staggered by one
-//     barrier: while one group issues LDS reads + DMA and waits, the other group's MFMA
-//     cluster owns the matrix pipe.
+//   LDS ring.  Every 64-wide K step is split into four 16-KiB UNITS
+//         u0 = A^0  rows    {wm*128 +      0..63}   (wm = 0,1)
+//         u1 = B^1  queries {wn*64  + 32 + 0..31}   (wn = 0..3)
+//         u2 = A^1  rows    {wm*128 + 64 + 0..63}
+//         u3 = B^0  queries {wn*64  +      0..31}
+//     held in 8 unit slots (128 KiB, slot = 4 * (kstep & 1) + u).  Slot p of K step s issues the
+//     global_load_lds of unit u_p of K step s+2 into the slot that unit u_p of K step s just
+//     vacated, so two K steps of DMA are always in flight.
 //
-// Filter placement: the filter of tile entry e runs at the top of entry e+1's first phase (its
-// VALU work overlaps the other group's MFMAs); what needs every wave's contribution (publishing
-// the boot maxima, list compaction) runs two phases later, when both groups' filter stores are
-// published (each storing wave drains its stores before its next barrier).  The global-bound
-// rows are fetched by LDS-DMA in phase 0 of an entry's first K step (older than the six
-// youngest DMA pieces at the phase-3 wait, hence retired by it) and folded one K step later.
+//   Registers.  The fragments a slot's MFMAs consume were read from LDS during the PREVIOUS
+//     slot; the reads a slot issues are for the NEXT slot and complete under this slot's 16
+//     MFMAs (two B register sets; ONE A set whose fragments are re-read one by one, each
+//     right after its last MFMA use, in the two slots where the A set dies).  Per K step s:
+//         slot 0: MFMA A^0 x B^0   | reads B^1(s)              | DMA A^0(s+2)
+//         slot 1: MFMA A^0 x B^1   | reads A^1(s)              | DMA B^1(s+2)
+//         slot 2: MFMA A^1 x B^1   | reads B^0(s) again        | DMA A^1(s+2), counted wait
+//         slot 3: MFMA A^1 x B^0   | reads A^0(s+1), B^0(s+1)  | DMA B^0(s+2)
+//     Each unit is overwritten in the slot after the one in which it was last read, and every
+//     wave retires its reads (lgkmcnt(0)) before the single barrier that closes a slot.
+//     ONE counted wait per K step: s_waitcnt vmcnt(6) at the end of slot 2 leaves the three
+//     units issued in slots 0-2 in flight and retires all of K step s+1, which slot 3 starts
+//     to read after the barrier.  The two B register sets swap roles every K step, so the
+//     loop body is two K steps (8 slots).
+//
+// Filter placement: the filter of tile entry e runs at the top of entry e+1's first slot; what
+// needs every wave's contribution (publishing the boot maxima, list compaction) runs one slot
+// later (each storing wave drains its stores before the barrier in between).  Global-bound
+// rows are fetched by LDS-DMA in slot 0 (older than the six youngest DMA pieces at the slot-2
+// wait, hence retired by it) and folded at the next K step.
 #include "scan_common.h"
 
 namespace sqe {
@@ -64,15 +68,176 @@ __device__ __forceinline__ bf16x8 unit_frag(const char* slot, int ru, int c) {
     return *reinterpret_cast<const bf16x8*>(slot + ru * SCAN_ROW_BYTES + ((c ^ ((ru >> 1) & 7)) << 4));
 }
 
+typedef bf16x8 AFrag[4][2];   // [fm][kk]: 64 rows x 64 k
+typedef bf16x8 BFrag[2][2];   // [fn][kk]: 32 queries x 64 k
+
+__device__ __forceinline__ void read_a(AFrag& a, const char* unit, int ruA, int cq) {
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a[fm][kk] = unit_frag(unit, ruA + fm * 16, kk * 4 + cq);
+}
+__device__ __forceinline__ void read_b(BFrag& b, const char* unit, int ruB, int cq) {
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) b[fn][kk] = unit_frag(unit, ruB + fn * 16, kk * 4 + cq);
+}
+
+template <int I0, int J0>
+__device__ __forceinline__ void mfma_quad(f32x4 (&acc)[8][4], const AFrag& a, const BFrag& b) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn)
+                acc[I0 + fm][J0 + fn] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[I0 + fm][J0 + fn], 0, 0, 0);
+}
+
+// Same quadrant, but the A set dies here: each A fragment is re-read from `next_unit` right
+// after its last MFMA use, so the next slot's A fragments arrive under this slot's MFMAs
+// without a second A register set.
+template <int I0, int J0>
+__device__ __forceinline__ void mfma_quad_refill(f32x4 (&acc)[8][4], AFrag& a, const BFrag& b,
+                                                 const char* next_unit, bool refill, int ruA, int cq) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn)
+                acc[I0 + fm][J0 + fn] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[I0 + fm][J0 + fn], 0, 0, 0);
+            if (refill) a[fm][kk] = unit_frag(next_unit, ruA + fm * 16, kk * 4 + cq);
+        }
+}
+
+struct Pipe {
+    // constants
+    const char* dbbase;
+    const char* qbase;
+    char* smem;
+    char* gstage;
+    const uint32_t* gmax_group;
+    size_t ld;
+    int offA[2], offB[2], a1_off, b1_off;
+    int ruA, ruB, cq;
+    int wave, lane, wm, wn;
+    int tile_begin, nt, KS, S;
+    int kp, trig, gshift, refresh_every;
+    // (entry, ks) of K steps s, s+1, s+2
+    int e0, ks0, e1, ks1, e2, ks2;
+    int refresh_pending, refresh_ctr;
+
+    __device__ __forceinline__ int tile_of(int e) const { return e < nt ? tile_begin + e : tile_begin; }
+    __device__ __forceinline__ const char* a_src(int e, int ks) const {
+        return dbbase + (size_t)tile_of(e) * SCAN_BM * ld + (size_t)ks * SCAN_ROW_BYTES;
+    }
+    __device__ __forceinline__ const char* b_src(int ks) const { return qbase + (size_t)ks * SCAN_ROW_BYTES; }
+    __device__ __forceinline__ char* slot_of(int s, int u) const { return smem + (((s & 1) << 2) + u) * UNIT_BYTES; }
+    __device__ __forceinline__ void advance() {
+        e0 = e1; ks0 = ks1;
+        e1 = e2; ks1 = ks2;
+        if (++ks2 == KS) { ks2 = 0; ++e2; }
+    }
+};
+
+// One K step.  On entry a = A^0(s) and bX = B^0(s) are in registers; on exit a = A^0(s+1)
+// and bY = B^0(s+1) are (the caller swaps bX / bY for the next K step).
+__device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][4], AFrag& a,
+                                      BFrag& bX, BFrag& bY, int s) {
+    char* u0 = P.slot_of(s, 0);
+    char* u1 = P.slot_of(s, 1);
+    char* u2 = P.slot_of(s, 2);
+    char* u3 = P.slot_of(s, 3);
+    const bool more2 = s + 2 < P.S;
+    const bool entry_start = P.ks0 == 0 && s > 0;
+
+    // ================= slot 0: A^0 x B^0
+    read_b(bY, u1, P.ruB, P.cq);
+    if (P.refresh_pending >= 0) {            // fetched during an earlier K step, retired by its slot-2 wait
+        refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.wave, fresh_lane());
+        P.refresh_pending = -1;
+    }
+    if (P.gshift >= 0 && P.e0 > 0 && (P.ks0 % P.refresh_every) == 0) {
+        P.refresh_pending = P.refresh_ctr % NSLICE8;
+        ++P.refresh_ctr;
+        refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
+    }
+    if (more2) issue_unit(P.a_src(P.e2, P.ks2), P.offA[0], P.offA[1], u0, P.wave);
+    if (P.ks0 == 0) {
+        if (s > 0) {
+            // filter of the entry finished by the previous K step
+            const int64_t row0 = (int64_t)P.tile_of(P.e0 - 1) * SCAN_BM;
+            const int fl = fresh_lane();
+            if (P.e0 - 1 == 0) {
+                filter_boot<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl);
+            } else if (filter_tile<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // publish appended keys
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quad<0, 0>(acc, a, bX);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SQE_BARRIER();
+
+    // ================= slot 1: A^0 x B^1
+    if (entry_start) {
+        // every wave's filter stores for the previous entry are published (drained before the barrier)
+        if (P.e0 - 1 == 0) {
+            publish_cmax(f, P.wave * 32, 32, fresh_lane());
+        } else if (__builtin_amdgcn_readfirstlane(f.flags[P.wave]) != 0) {
+            const int fl = fresh_lane();
+            if (fl == 0) f.flags[P.wave] = 0;
+            compact_owned(f, P.wave * 32, 32, P.trig, P.kp, fl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more2) issue_unit(P.b_src(P.ks2) + P.b1_off, P.offB[0], P.offB[1], u1, P.wave);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quad_refill<0, 2>(acc, a, bY, u2, true, P.ruA, P.cq);          // a <- A^1(s)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SQE_BARRIER();
+
+    // ================= slot 2: A^1 x B^1; K step s+1 retired
+    read_b(bX, u3, P.ruB, P.cq);
+    if (more2) issue_unit(P.a_src(P.e2, P.ks2) + P.a1_off, P.offA[0], P.offA[1], u2, P.wave);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quad<4, 2>(acc, a, bY);
+    if (more2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    SQE_BARRIER();
+
+    // ================= slot 3: A^1 x B^0; fragments of K step s+1
+    const bool more1 = s + 1 < P.S;
+    if (more1) read_b(bY, P.slot_of(s + 1, 3), P.ruB, P.cq);
+    if (more2) issue_unit(P.b_src(P.ks2), P.offB[0], P.offB[1], u3, P.wave);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quad_refill<4, 0>(acc, a, bX, P.slot_of(s + 1, 0), more1, P.ruA, P.cq);   // a <- A^0(s+1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SQE_BARRIER();
+
+    P.advance();
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* gstage = smem + OFF_F + FL8::OFF_GSTAGE;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2;      // wave row (group): waves 0-3 / 4-7, one of each per SIMD
-    const int wn = wave & 3;
+    Pipe P;
+    P.lane = tid & 63;
+    P.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    P.wm = P.wave >> 2;
+    P.wn = P.wave & 3;
+    P.smem = smem;
+    P.gstage = smem + OFF_F + FL8::OFF_GSTAGE;
 
     int logical = blockIdx.x;
     const int G = gridDim.x;
@@ -81,21 +246,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     const int qb = logical % p.qblocks;
     const int q0 = qb * BN8;
 
-    const int tile_begin = chunk * p.tiles_per_chunk;
-    const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
-    const int nt = tile_end - tile_begin;
-    const int KS = p.K / SCAN_BK;
+    P.tile_begin = chunk * p.tiles_per_chunk;
+    const int tile_end = min(p.n_tiles, P.tile_begin + p.tiles_per_chunk);
+    P.nt = tile_end - P.tile_begin;
+    P.KS = p.K / SCAN_BK;
     // entries: 0 = first tile (BOOT), 1..nt-1 = the other tiles, nt = the first tile again
-    const int n_entries = nt > 0 ? nt + 1 : 0;
-    const int S = n_entries * KS;                    // K steps of this workgroup
-    const size_t ld = (size_t)p.K * 2;
-    auto tile_of = [&](int e) { return e < nt ? tile_begin + e : tile_begin; };
+    const int n_entries = P.nt > 0 ? P.nt + 1 : 0;
+    P.S = n_entries * P.KS;
+    P.ld = (size_t)p.K * 2;
+    P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift;
+    P.refresh_every = P.KS >= NSLICE8 ? P.KS / NSLICE8 : 1;
 
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
     f.gstride = p.ngroups * GMAX_COLS;
-    const uint32_t* gmax_group = p.gmax + ((size_t)q0 * p.ngroups + (chunk % p.ngroups)) * GMAX_COLS;
-    f.gmax_mine = const_cast<uint32_t*>(gmax_group) + chunk / p.ngroups;
+    P.gmax_group = p.gmax + ((size_t)q0 * p.ngroups + (chunk % p.ngroups)) * GMAX_COLS;
+    f.gmax_mine = const_cast<uint32_t*>(P.gmax_group) + chunk / p.ngroups;
     f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL8::OFF_THR_KEY);
     f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL8::OFF_THR_S);
     f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL8::OFF_CNT);
@@ -115,190 +281,68 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     if (tid < 16) f.flags[tid] = 0;
 
     // ---- per-lane source offsets of this wave's two DMA pieces per unit (h = 0 form)
-    int offA[2], offB[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int ru = (wave + 8 * t) * 8 + (lane >> 3);        // unit row 0..127
-        const int c = (lane & 7) ^ ((ru >> 1) & 7);             // source chunk (swizzle on the source)
-        offA[t] = (int)(((ru >> 6) * 128 + (ru & 63)) * ld) + c * 16;
-        offB[t] = (int)(((ru >> 5) * 64 + (ru & 31)) * ld) + c * 16;
+        const int ru = (P.wave + 8 * t) * 8 + (P.lane >> 3);      // unit row 0..127
+        const int c = (P.lane & 7) ^ ((ru >> 1) & 7);             // source chunk (swizzle on the source)
+        P.offA[t] = (int)(((ru >> 6) * 128 + (ru & 63)) * P.ld) + c * 16;
+        P.offB[t] = (int)(((ru >> 5) * 64 + (ru & 31)) * P.ld) + c * 16;
     }
-    const int a1_off = (int)(64 * ld);     // A^1 = A^0 + 64 rows
-    const int b1_off = (int)(32 * ld);     // B^1 = B^0 + 32 queries
+    P.a1_off = (int)(64 * P.ld);     // A^1 = A^0 + 64 rows
+    P.b1_off = (int)(32 * P.ld);     // B^1 = B^0 + 32 queries
+    P.qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * P.ld;
+    P.dbbase = reinterpret_cast<const char*>(p.db);
+    P.ruA = P.wm * 64 + (P.lane & 15);
+    P.ruB = P.wn * 32 + (P.lane & 15);
+    P.cq = P.lane >> 4;
 
-    const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ld;
-    const char* dbbase = reinterpret_cast<const char*>(p.db);
-    auto a_src = [&](int e, int ks) { return dbbase + (size_t)tile_of(e) * SCAN_BM * ld + (size_t)ks * SCAN_ROW_BYTES; };
-    auto b_src = [&](int ks) { return qbase + (size_t)ks * SCAN_ROW_BYTES; };
-    auto slot_of = [&](int s, int u) { return smem + (((s & 1) << 2) + u) * UNIT_BYTES; };
-
-    // ---- fragment read addressing (unit rows of this wave)
-    const int ruA = wm * 64 + (lane & 15);     // + fm * 16
-    const int ruB = wn * 32 + (lane & 15);     // + fn * 16
-    const int cq = lane >> 4;                  // + kk * 4
+    P.e0 = 0; P.ks0 = 0;
+    P.e1 = 0; P.ks1 = 1;
+    if (P.ks1 == P.KS) { P.ks1 = 0; ++P.e1; }
+    P.e2 = P.e1; P.ks2 = P.ks1 + 1;
+    if (P.ks2 == P.KS) { P.ks2 = 0; ++P.e2; }
+    P.refresh_pending = -1;
+    P.refresh_ctr = 0;
 
     f32x4 acc[8][4];
-    bf16x8 a[4][2], b[2][2];
+    AFrag a;
+    BFrag bX, bY;
 
-    // (entry, ks) of K steps s, s+1, s+2
-    int e0 = 0, ks0 = 0;
-    int e1 = 0, ks1 = 1;
-    if (ks1 == KS) { ks1 = 0; ++e1; }
-    int e2 = e1, ks2 = ks1 + 1;
-    if (ks2 == KS) { ks2 = 0; ++e2; }
-
-    // ---- prologue: K step 0 (all four units) and K step 1 (u0..u2)
-    if (S > 0) {
-        const char* a0 = a_src(0, 0);
-        const char* b0 = b_src(0);
-        issue_unit(a0, offA[0], offA[1], slot_of(0, 0), wave);
-        issue_unit(b0 + b1_off, offB[0], offB[1], slot_of(0, 1), wave);
-        issue_unit(a0 + a1_off, offA[0], offA[1], slot_of(0, 2), wave);
-        issue_unit(b0, offB[0], offB[1], slot_of(0, 3), wave);
-        const char* a1 = a_src(e1, ks1);      // S >= 2 whenever S > 0 (boot + rescan entries)
-        const char* b1p = b_src(ks1);
-        issue_unit(a1, offA[0], offA[1], slot_of(1, 0), wave);
-        issue_unit(b1p + b1_off, offB[0], offB[1], slot_of(1, 1), wave);
-        issue_unit(a1 + a1_off, offA[0], offA[1], slot_of(1, 2), wave);
+    // ---- prologue: all units of K steps 0 and 1 (S >= 2 whenever S > 0: boot + rescan entries)
+    if (P.S > 0) {
+        const char* a0 = P.a_src(0, 0);
+        const char* b0 = P.b_src(0);
+        issue_unit(a0, P.offA[0], P.offA[1], P.slot_of(0, 0), P.wave);
+        issue_unit(b0 + P.b1_off, P.offB[0], P.offB[1], P.slot_of(0, 1), P.wave);
+        issue_unit(a0 + P.a1_off, P.offA[0], P.offA[1], P.slot_of(0, 2), P.wave);
+        issue_unit(b0, P.offB[0], P.offB[1], P.slot_of(0, 3), P.wave);
+        const char* a1 = P.a_src(P.e1, P.ks1);
+        const char* b1 = P.b_src(P.ks1);
+        issue_unit(a1, P.offA[0], P.offA[1], P.slot_of(1, 0), P.wave);
+        issue_unit(b1 + P.b1_off, P.offB[0], P.offB[1], P.slot_of(1, 1), P.wave);
+        issue_unit(a1 + P.a1_off, P.offA[0], P.offA[1], P.slot_of(1, 2), P.wave);
+        issue_unit(b1, P.offB[0], P.offB[1], P.slot_of(1, 3), P.wave);
     }
     __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
-    if (wm == 1) SQE_BARRIER();            // stagger: group 1 runs one barrier behind group 0
-
-    int refresh_pending = -1;
-    int refresh_ctr = 0;
-    for (int s = 0; s < S; ++s) {
-        const char* u0 = slot_of(s, 0);
-        const char* u1 = slot_of(s, 1);
-        const char* u2 = slot_of(s, 2);
-        const char* u3 = slot_of(s, 3);
-        const bool entry_start = ks0 == 0 && s > 0;
-
-        // ================= phase 0: quadrant (A^0, B^0); loads (s+1, u3)
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b[fn][kk] = unit_frag(u3, ruB + fn * 16, kk * 4 + cq);
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) a[fm][kk] = unit_frag(u0, ruA + fm * 16, kk * 4 + cq);
-        if (refresh_pending >= 0) {          // fetched during the previous K step, retired by its phase-3 wait
-            refresh_apply(f, gstage, refresh_pending, p.gshift, wave, lane);
-            refresh_pending = -1;
-        }
-        if (entry_start && p.gshift >= 0) {  // one slice of the global bound per tile entry
-            refresh_pending = refresh_ctr % NSLICE8;
-            ++refresh_ctr;
-            refresh_issue(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
-        }
-        if (s + 1 < S) issue_unit(b_src(ks1), offB[0], offB[1], const_cast<char*>(slot_of(s + 1, 3)), wave);
-        if (ks0 == 0) {
-            if (s > 0) {
-                // filter of the entry finished by the previous K step
-                const int64_t row0 = (int64_t)tile_of(e0 - 1) * SCAN_BM;
-                if (e0 - 1 == 0) {
-                    filter_boot<8, 4>(acc, f, row0, wm * 128, wn * 64, lane);
-                } else if (filter_tile<8, 4>(acc, f, row0, wm * 128, wn * 64, lane)) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // publish appended keys
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    if (P.S > 0) {
+        read_a(a, P.slot_of(0, 0), P.ruA, P.cq);
+        read_b(bX, P.slot_of(0, 3), P.ruB, P.cq);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SQE_BARRIER();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[fm][fn], 0, 0, 0);
-        SQE_BARRIER();
+    }
+    SQE_BARRIER();                         // every wave holds its first fragments before slot 0 reuses u0
 
-        // ================= phase 1: quadrant (A^0, B^1); u0 is dead -> (s+2, u0)
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b[fn][kk] = unit_frag(u1, ruB + fn * 16, kk * 4 + cq);
-        if (s + 2 < S) issue_unit(a_src(e2, ks2), offA[0], offA[1], const_cast<char*>(u0), wave);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SQE_BARRIER();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn)
-                    acc[fm][2 + fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[fm][2 + fn], 0, 0, 0);
-        SQE_BARRIER();
-
-        // ================= phase 2: quadrant (A^1, B^1); u1 is dead -> (s+2, u1)
-        if (entry_start) {
-            // both groups' filter stores for the previous entry are published by now.  Done before
-            // the A^1 fragment reads so the sweep's registers do not stack on top of them; the flag
-            // word has a wave-uniform address (no per-lane address kept alive across the loop).
-            if (e0 - 1 == 0) {
-                publish_cmax(f, wave * 32, 32, lane);
-            } else if (__builtin_amdgcn_readfirstlane(f.flags[wave]) != 0) {
-                if (lane == 0) f.flags[wave] = 0;
-                compact_owned(f, wave * 32, 32, p.trig, p.kp, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) a[fm][kk] = unit_frag(u2, ruA + fm * 16, kk * 4 + cq);
-        if (s + 2 < S) issue_unit(b_src(ks2) + b1_off, offB[0], offB[1], const_cast<char*>(u1), wave);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SQE_BARRIER();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn)
-                    acc[4 + fm][2 + fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[4 + fm][2 + fn], 0, 0, 0);
-        SQE_BARRIER();
-
-        // ================= phase 3: quadrant (A^1, B^0); u2 is dead -> (s+2, u2); K step s+1 retired
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b[fn][kk] = unit_frag(u3, ruB + fn * 16, kk * 4 + cq);
-        if (s + 2 < S) {
-            issue_unit(a_src(e2, ks2) + a1_off, offA[0], offA[1], const_cast<char*>(u2), wave);
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        SQE_BARRIER();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn)
-                    acc[4 + fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[4 + fm][fn], 0, 0, 0);
-        SQE_BARRIER();
-
-        // advance the (entry, ks) windows
-        e0 = e1; ks0 = ks1;
-        e1 = e2; ks1 = ks2;
-        if (++ks2 == KS) { ks2 = 0; ++e2; }
+    for (int s = 0; s < P.S; s += 2) {
+        kstep(P, f, acc, a, bX, bY, s);
+        if (s + 1 < P.S) kstep(P, f, acc, a, bY, bX, s + 1);
     }
 
-    // ---- tail: filter of the last entry (the rescan of the first tile, or nothing)
-    if (S > 0) {
-        if (filter_tile<8, 4>(acc, f, (int64_t)tile_begin * SCAN_BM, wm * 128, wn * 64, lane))
+    // ---- tail: filter of the last entry (the rescan of the first tile)
+    if (P.S > 0) {
+        if (filter_tile<8, 4>(acc, f, (int64_t)P.tile_begin * SCAN_BM, P.wm * 128, P.wn * 64, P.lane))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (wm == 0) SQE_BARRIER();            // undo the stagger
     __syncthreads();
-    compact_owned(f, wave * 32, 32, p.kp + 1, p.kp, lane);
+    compact_owned(f, P.wave * 32, 32, p.kp + 1, p.kp, P.lane);
     __syncthreads();
     for (int i = tid; i < BN8; i += SCAN_THREADS)
         p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];

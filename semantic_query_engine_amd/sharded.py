@@ -6,16 +6,15 @@ all-gather of the packed per-shard results over RCCL/xGMI (120 KB per rank at B=
 k=10: latency-bound, so a single collective) -> merge kernel (ties to the lowest global
 id).  With world == 1 there is no collective.
 
-The library context is switched onto torch's current stream so the scan, the collective
-and the merge are ordered on the device without host synchronisation.
+On a GPU the library context is switched onto a dedicated torch stream so the scan, the
+collective and the merge are ordered on the device without host synchronisation.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional, Tuple
 
 import torch
-
-from .engine import Context, VectorIndex
 
 
 def packed_part_bytes(b: int, k: int) -> int:
@@ -23,16 +22,31 @@ def packed_part_bytes(b: int, k: int) -> int:
     return (b * k * 12 + 15) // 16 * 16
 
 
+def shard_rows(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of the global index owned by `rank` (contiguous, ceil-divided)."""
+    per = (n_total + world - 1) // world
+    return min(n_total, rank * per), min(n_total, (rank + 1) * per)
+
+
 class ShardedSearcher:
-    def __init__(self, ctx: Context, index: VectorIndex, id_base: int = 0, dist=None, world: int = 1,
+    """`ctx` / `index` are the engine objects (Context / VectorIndex); anything exposing the same
+    ``search_device`` / ``merge_topk_device`` / ``set_option`` / ``set_stream`` calls works,
+    which is how the CPU/gloo protocol tests drive this class without a GPU."""
+
+    def __init__(self, ctx, index, id_base: int = 0, dist=None, world: int = 1,
                  device: Optional[torch.device] = None, group=None):
         self.ctx, self.index, self.dist, self.world, self.group = ctx, index, dist, world, group
         self.device = device or torch.device("cuda", ctx.device)
         index.set_option("id_base", float(id_base))
         self._bufs = {}
-        # a dedicated torch stream (the default stream's handle is 0 = "no stream" to the ABI)
-        self.stream = torch.cuda.Stream(self.device)
-        ctx.set_stream(self.stream.cuda_stream)
+        self.stream = None
+        if self.device.type == "cuda":
+            # a dedicated torch stream (the default stream's handle is 0 = "no stream" to the ABI)
+            self.stream = torch.cuda.Stream(self.device)
+            ctx.set_stream(self.stream.cuda_stream)
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _buffers(self, b: int, k: int):
         key = (b, k)
@@ -53,7 +67,7 @@ class ShardedSearcher:
         part, local, gathered, cos, ids = self._buffers(b, k)
         id_ptr = local.data_ptr()
         cos_ptr = id_ptr + b * k * 8
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             if self.world == 1:
                 self.index.search_device(q.data_ptr(), b, k, cos.data_ptr(), ids.data_ptr())
                 return cos, ids
@@ -64,4 +78,5 @@ class ShardedSearcher:
         return cos, ids
 
     def synchronize(self) -> None:
-        self.stream.synchronize()
+        if self.stream is not None:
+            self.stream.synchronize()
