@@ -87,8 +87,10 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     int logical = blockIdx.x;
     const int G = gridDim.x;
     if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int chunk = logical / p.qblocks;
-    const int qb = logical % p.qblocks;
+    // integer division runs on the VALU: pull the (uniform) results back into SGPRs so that
+    // everything derived from them (tile range, base pointers) stays scalar
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
     const int q0 = qb * BN;
 
     const int tile_begin = chunk * p.tiles_per_chunk;

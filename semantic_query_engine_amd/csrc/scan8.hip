@@ -59,7 +59,7 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 }
 
 // one unit = 16 wave-instructions of 1 KiB; wave w issues pieces w and w + 8
-__device__ __forceinline__ void issue_unit(const char* gbase, int off0, int off1, char* slot, int wave) {
+__device__ __forceinline__ void issue_unit(const char* gbase, unsigned off0, unsigned off1, char* slot, int wave) {
     glds16(gbase + off0, slot + wave * 1024);
     glds16(gbase + off1, slot + (wave + 8) * 1024);
 }
@@ -122,7 +122,8 @@ struct Pipe {
     char* gstage;
     const uint32_t* gmax_group;
     size_t ld;
-    int offA[2], offB[2], a1_off, b1_off;
+    unsigned offA[2], offB[2];     // per-lane byte offsets (zero-extended: SGPR-base addressing form)
+    unsigned a1_off, b1_off;        // uniform
     int ruA, ruB, cq;
     int wave, lane, wm, wn;
     int tile_begin, nt, KS, S;
@@ -242,8 +243,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     int logical = blockIdx.x;
     const int G = gridDim.x;
     if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int chunk = logical / p.qblocks;
-    const int qb = logical % p.qblocks;
+    // integer division runs on the VALU: pull the (uniform) results back into SGPRs so that
+    // everything derived from them (tile range, base pointers) stays scalar
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
     const int q0 = qb * BN8;
 
     P.tile_begin = chunk * p.tiles_per_chunk;
@@ -285,11 +288,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     for (int t = 0; t < 2; ++t) {
         const int ru = (P.wave + 8 * t) * 8 + (P.lane >> 3);      // unit row 0..127
         const int c = (P.lane & 7) ^ ((ru >> 1) & 7);             // source chunk (swizzle on the source)
-        P.offA[t] = (int)(((ru >> 6) * 128 + (ru & 63)) * P.ld) + c * 16;
-        P.offB[t] = (int)(((ru >> 5) * 64 + (ru & 31)) * P.ld) + c * 16;
+        P.offA[t] = (unsigned)(((ru >> 6) * 128 + (ru & 63)) * P.ld) + c * 16;
+        P.offB[t] = (unsigned)(((ru >> 5) * 64 + (ru & 31)) * P.ld) + c * 16;
     }
-    P.a1_off = (int)(64 * P.ld);     // A^1 = A^0 + 64 rows
-    P.b1_off = (int)(32 * P.ld);     // B^1 = B^0 + 32 queries
+    P.a1_off = (unsigned)(64 * P.ld);     // A^1 = A^0 + 64 rows
+    P.b1_off = (unsigned)(32 * P.ld);     // B^1 = B^0 + 32 queries
     P.qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * P.ld;
     P.dbbase = reinterpret_cast<const char*>(p.db);
     P.ruA = P.wm * 64 + (P.lane & 15);
