@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of include/sqe.h: context, flat vector index, search pipeline,
 // cache scan and stats.  No C++ types or exceptions cross this boundary.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -125,7 +126,8 @@ struct sqe_index {
     int64_t n = 0;
     int64_t cap = 0;               // rows allocated (multiple of 256)
     float* master = nullptr;       // [cap, dim] fp32 normalised
-    bf16_t* scan = nullptr;        // [cap, dim] bf16 normalised, zero past n
+    bf16_t* scan = nullptr;        // [cap] rows of dim bf16 at `pitch` bytes, zero past n
+    int pitch = 0;                 // bytes between rows of the scanned copy and of the bf16 query block
     int scan_mode = SQE_SCAN_BF16_RESCORE;
     int rescore_k = 0;             // 0 = automatic
     int nprobe = 0;
@@ -162,7 +164,7 @@ int index_grow(sqe_index* idx, int64_t need_rows) {
     sqe_ctx* c = idx->ctx;
     int64_t new_cap = std::max<int64_t>(need_rows, idx->cap + idx->cap / 2);
     new_cap = round_up(std::max<int64_t>(new_cap, 1024), SCAN_BM);
-    const size_t row_f = (size_t)idx->dim * 4, row_b = (size_t)idx->dim * 2;
+    const size_t row_f = (size_t)idx->dim * 4, row_b = (size_t)idx->pitch;
     float* nm = nullptr;
     bf16_t* ns = nullptr;
     hipError_t e = hipMalloc((void**)&nm, (size_t)new_cap * row_f);
@@ -275,6 +277,13 @@ int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out
     idx->dim = dim;
     idx->kind = kind;
     idx->nlist = nlist;
+    {
+        // rows of the scanned copy are padded by one 128-B line by default: with a 2^n pitch every
+        // row of a K slice would sit in the same memory channel
+        const char* e = getenv("SQE_ROW_PAD");
+        const int pad = e ? atoi(e) : 128;
+        idx->pitch = dim * 2 + (pad >= 0 && pad % 8 == 0 ? pad : 128);
+    }
     *out = idx;
     return SQE_OK;
 }
@@ -309,7 +318,7 @@ int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n) {
     {
         StageTimer t(idx->ctx->prof, idx->ctx->stream, ST_ADD);
         SQE_TRY(launch_normalize_rows(x_dev, n, idx->dim, idx->master + (size_t)idx->n * idx->dim,
-                                      idx->scan + (size_t)idx->n * idx->dim, idx->ctx->stream));
+                                      idx->scan + (size_t)idx->n * (idx->pitch / 2), idx->pitch / 2, idx->ctx->stream));
     }
     idx->n += n;
     return SQE_OK;
@@ -347,7 +356,7 @@ int sqe_index_update(sqe_index* idx, const int64_t* rows_host, const float* x_ho
     SQE_HIP(hipMemcpyAsync(c->stage_in.p, x_host, xb, hipMemcpyHostToDevice, c->stream));
     SQE_HIP(hipMemcpyAsync((char*)c->stage_in.p + xb, rows_host, rb, hipMemcpyHostToDevice, c->stream));
     SQE_TRY(launch_normalize_rows_scatter(c->stage_in.as<float>(), (const int64_t*)((char*)c->stage_in.p + xb), n,
-                                          idx->dim, idx->master, idx->scan, c->stream));
+                                          idx->dim, idx->master, idx->scan, idx->pitch / 2, c->stream));
     SQE_HIP(hipStreamSynchronize(c->stream));
     return SQE_OK;
 }
@@ -408,7 +417,7 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     const ScanPlan plan = make_scan_plan(idx->n, B, kp, c->cu_count);
 
     SQE_TRY(idx->qn.ensure((size_t)B * K * 4));
-    SQE_TRY(idx->qb.ensure((size_t)plan.b_pad * K * 2));
+    SQE_TRY(idx->qb.ensure((size_t)plan.b_pad * idx->pitch));
     SQE_TRY(idx->cand.ensure((size_t)plan.n_chunks * plan.b_pad * CAND_CAP * 8));
     SQE_TRY(idx->cand_cnt.ensure((size_t)plan.n_chunks * plan.b_pad * 4));
     const size_t gmax_bytes = (size_t)plan.b_pad * plan.ngroups * GMAX_COLS * 4;
@@ -416,14 +425,15 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     {
         StageTimer t(c->prof, c->stream, ST_PREP);
         if (plan.b_pad > B)
-            SQE_HIP(hipMemsetAsync(idx->qb.as<char>() + (size_t)B * K * 2, 0, (size_t)(plan.b_pad - B) * K * 2, c->stream));
-        SQE_TRY(launch_normalize_rows(q_dev, B, K, idx->qn.as<float>(), idx->qb.as<bf16_t>(), c->stream));
+            SQE_HIP(hipMemsetAsync(idx->qb.as<char>() + (size_t)B * idx->pitch, 0, (size_t)(plan.b_pad - B) * idx->pitch, c->stream));
+        SQE_TRY(launch_normalize_rows(q_dev, B, K, idx->qn.as<float>(), idx->qb.as<bf16_t>(), idx->pitch / 2, c->stream));
         SQE_HIP(hipMemsetAsync(idx->gmax.p, 0, gmax_bytes, c->stream));
     }
     if (idx->n > 0) {
         StageTimer t(c->prof, c->stream, ST_SCAN);
         ScanArgs a;
         a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
+        a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
         a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
         SQE_TRY(launch_scan_bf16(plan, a, c->stream));
     } else {

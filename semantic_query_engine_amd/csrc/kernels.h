@@ -8,11 +8,13 @@ namespace sqe {
 // ------------------------------------------------------------------ normalise (S1)
 // out = x / (||x||_2 + 1e-9) per row, fp32 (main.py:315-316, 353-354); optionally also a
 // bf16 copy (the scanned copy).  Either output may be null.  dim % 4 == 0.
+// `bf16_pitch` = elements between consecutive bf16 output rows (>= dim; the scanned copy pads
+// its rows so that consecutive rows do not map to the same memory channel).
 int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
-                          hipStream_t stream);
+                          int bf16_pitch, hipStream_t stream);
 // Same, rows scattered to out row ids `rows[i]` (sqe_index_update).
 int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
-                                  float* out_f32, bf16_t* out_bf16, hipStream_t stream);
+                                  float* out_f32, bf16_t* out_bf16, int bf16_pitch, hipStream_t stream);
 
 // ------------------------------------------------------------------ flat scan (S2)
 constexpr int SCAN_BM = 256;        // DB rows per tile
@@ -35,8 +37,9 @@ struct ScanPlan {
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count);
 
 struct ScanArgs {
-    const bf16_t* db;     // [round_up(n_rows, 256), K] bf16, zero rows past n_rows
-    const bf16_t* q;      // [b_pad, K] bf16, zero rows past B
+    const bf16_t* db;     // [round_up(n_rows, 256)] rows of K bf16 at `db_pitch` bytes, zero rows past n_rows
+    const bf16_t* q;      // [b_pad] rows of K bf16 at `q_pitch` bytes, zero rows past B
+    int db_pitch, q_pitch;
     int64_t n_rows;
     int K;
     int B;

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
                                                              const int64_t* __restrict__ rows,
                                                              int64_t n, int dim,
                                                              float* __restrict__ out_f32,
-                                                             bf16_t* __restrict__ out_bf16) {
+                                                             bf16_t* __restrict__ out_bf16, int bf16_pitch) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     const float den = sqrtf(ss) + 1e-9f;
     const int64_t orow = SCATTER ? rows[row] : row;
     float4* dst = out_f32 ? reinterpret_cast<float4*>(out_f32 + orow * dim) : nullptr;
-    uint2* dstb = out_bf16 ? reinterpret_cast<uint2*>(out_bf16 + orow * dim) : nullptr;
+    uint2* dstb = out_bf16 ? reinterpret_cast<uint2*>(out_bf16 + orow * bf16_pitch) : nullptr;
     for (int i = lane; i < nvec; i += 64) {
         float4 v = src[i];   // second read is an L1/L2 hit (row = 4 KiB at dim 1024)
         v.x /= den; v.y /= den; v.z /= den; v.w /= den;
@@ -43,24 +43,25 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 }
 
 int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
-                          hipStream_t stream) {
+                          int bf16_pitch, hipStream_t stream) {
     if (n <= 0) return SQE_OK;
-    if (dim % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: dim must be a multiple of 4");
+    if (dim % 4 != 0 || bf16_pitch % 4 != 0 || bf16_pitch < dim)
+        return fail(SQE_ERR_INVALID, "normalize: dim and pitch must be multiples of 4, pitch >= dim");
     const int64_t blocks = (n + 3) / 4;
     if (blocks > 0x7fffffffLL) return fail(SQE_ERR_INVALID, "normalize: too many rows for one launch");
     hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       x, (const int64_t*)nullptr, n, dim, out_f32, out_bf16);
+                       x, (const int64_t*)nullptr, n, dim, out_f32, out_bf16, bf16_pitch);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
 
 int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
-                                  float* out_f32, bf16_t* out_bf16, hipStream_t stream) {
+                                  float* out_f32, bf16_t* out_bf16, int bf16_pitch, hipStream_t stream) {
     if (n <= 0) return SQE_OK;
     if (dim % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: dim must be a multiple of 4");
     const int64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(normalize_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       x, rows, n, dim, out_f32, out_bf16);
+                       x, rows, n, dim, out_f32, out_bf16, bf16_pitch);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

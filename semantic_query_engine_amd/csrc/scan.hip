@@ -97,13 +97,13 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
     const int nt = tile_end - tile_begin;
     const int KS = p.K / SCAN_BK;
-    const size_t ld_bytes = (size_t)p.K * 2;
+    const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
 
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
-    f.gstride = p.ngroups * GMAX_COLS;
-    const uint32_t* gmax_group = p.gmax + ((size_t)q0 * p.ngroups + (chunk % p.ngroups)) * GMAX_COLS;
-    f.gmax_mine = const_cast<uint32_t*>(gmax_group) + chunk / p.ngroups;
+    f.gstride = p.ngroups * GMAX_COLS * 64;
+    const uint32_t* gmax_group = p.gmax + ((size_t)(q0 / 64) * p.ngroups + (chunk % p.ngroups)) * (GMAX_COLS * 64);
+    f.gmax_mine = const_cast<uint32_t*>(gmax_group) + (chunk / p.ngroups) * 64;
     f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL::OFF_THR_KEY);
     f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL::OFF_THR_S);
     f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL::OFF_CNT);
@@ -126,15 +126,19 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     // nt = the first tile again, normally.  (nt == 0: nothing.)
     const int n_entries = nt > 0 ? nt + 1 : 0;
     const int total_stages = n_entries * KS;
-    const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ld_bytes;
+    const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ldB;
     const char* dbbase = reinterpret_cast<const char*>(p.db);
     auto tile_of = [&](int e) { return e < nt ? tile_begin + e : tile_begin; };
+    // K step ks covers k slice (ks + rot) mod KS: query blocks sharing a DB tile walk K in rotated
+    // order and touch the same DB lines one K step apart (the dot product is order independent)
+    const int rot = (logical * p.krot) % KS;
+    auto kslice = [&](int k) { const int r = k + rot; return r >= KS ? r - KS : r; };
 
     f32x4 acc[FM][FN];
 
     if (total_stages > 0) {
-        stage_tile<BM>(dbbase + (size_t)tile_begin * BM * ld_bytes, ld_bytes, smem, wave, lane);
-        stage_tile<BN>(qbase, ld_bytes, smem + BM * ROW_BYTES, wave, lane);
+        stage_tile<BM>(dbbase + (size_t)tile_begin * BM * ldA + (size_t)kslice(0) * ROW_BYTES, ldA, smem, wave, lane);
+        stage_tile<BN>(qbase + (size_t)kslice(0) * ROW_BYTES, ldB, smem + BM * ROW_BYTES, wave, lane);
     }
     __syncthreads();   // vmcnt(0) + barrier: stage 0 landed, state initialised
 
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         char* cur = smem + (s & 1) * STAGE_BYTES;
         // the bound rows fetched during the previous K step have landed (barrier below)
         if (refresh_pending >= 0) {
-            refresh_apply(f, gstage, refresh_pending, p.gshift, wave, lane);
+            if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, lane);
             refresh_pending = -1;
         }
         // prefetch the next stage into the other buffer (its readers finished before the
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             int nentry = entry, nks = ks + 1;
             if (nks == KS) { nks = 0; ++nentry; }
             char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
-            stage_tile<BM>(dbbase + (size_t)tile_of(nentry) * BM * ld_bytes + (size_t)nks * ROW_BYTES, ld_bytes, nxt, wave, lane);
-            stage_tile<BN>(qbase + (size_t)nks * ROW_BYTES, ld_bytes, nxt + BM * ROW_BYTES, wave, lane);
+            stage_tile<BM>(dbbase + (size_t)tile_of(nentry) * BM * ldA + (size_t)kslice(nks) * ROW_BYTES, ldA, nxt, wave, lane);
+            stage_tile<BN>(qbase + (size_t)kslice(nks) * ROW_BYTES, ldB, nxt + BM * ROW_BYTES, wave, lane);
         }
         if (ks == 0) {
             if (entry > 0 && p.gshift >= 0) {       // one slice of the global bound per tile
@@ -235,10 +239,17 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
 ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     ScanKernelArgs k;
     k.db = a.db; k.q = a.q; k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = plan.b_pad;
+    k.db_pitch = a.db_pitch; k.q_pitch = a.q_pitch;
     k.n_tiles = plan.n_tiles; k.tiles_per_chunk = plan.tiles_per_chunk; k.n_chunks = plan.n_chunks;
     k.qblocks = plan.qblocks; k.kp = plan.kp;
     k.trig = plan.kp > 128 ? plan.kp : 128;
     k.ngroups = plan.ngroups; k.gshift = plan.gshift;
+    {
+        static const int krot = [] { const char* e = getenv("SQE_KROT"); return e ? atoi(e) : 0; }();
+        static const int dbg = [] { const char* e = getenv("SQE_DBG"); return e ? atoi(e) : 0; }();
+        k.krot = krot;
+        k.dbg = dbg;
+    }
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax;
     return k;
 }

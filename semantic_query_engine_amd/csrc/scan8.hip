@@ -121,27 +121,43 @@ struct Pipe {
     char* smem;
     char* gstage;
     const uint32_t* gmax_group;
-    size_t ld;
+    size_t ldA, ldB;               // row pitches (bytes) of the scanned DB copy and of the query block
     unsigned offA[2], offB[2];     // per-lane byte offsets (zero-extended: SGPR-base addressing form)
     unsigned a1_off, b1_off;        // uniform
     int ruA, ruB, cq;
     int wave, lane, wm, wn;
     int tile_begin, nt, KS, S;
     int kp, trig, gshift, refresh_every;
+    int rot;                        // K-loop rotation of this query block (see kernel comment)
+    bool no_mma, no_dma, no_filter; // timing experiments (SQE_DBG)
     // (entry, ks) of K steps s, s+1, s+2
     int e0, ks0, e1, ks1, e2, ks2;
     int refresh_pending, refresh_ctr;
+    // incremental source pointers of K step s+2
+    const char* tile2; const char* a2; const char* b2; long long tile_bytes; int ksl2;
 
     __device__ __forceinline__ int tile_of(int e) const { return e < nt ? tile_begin + e : tile_begin; }
+    // K step ks of this workgroup covers k slice (ks + rot) mod KS: workgroups walk K in rotated
+    // order (the dot product does not depend on the order).
+    __device__ __forceinline__ int kslice(int ks) const { const int k = ks + rot; return k >= KS ? k - KS : k; }
     __device__ __forceinline__ const char* a_src(int e, int ks) const {
-        return dbbase + (size_t)tile_of(e) * SCAN_BM * ld + (size_t)ks * SCAN_ROW_BYTES;
+        return dbbase + (size_t)tile_of(e) * SCAN_BM * ldA + (size_t)kslice(ks) * SCAN_ROW_BYTES;
     }
-    __device__ __forceinline__ const char* b_src(int ks) const { return qbase + (size_t)ks * SCAN_ROW_BYTES; }
+    __device__ __forceinline__ const char* b_src(int ks) const { return qbase + (size_t)kslice(ks) * SCAN_ROW_BYTES; }
     __device__ __forceinline__ char* slot_of(int s, int u) const { return smem + (((s & 1) << 2) + u) * UNIT_BYTES; }
+    // a2 / b2: source of K step s+2, maintained incrementally (a handful of scalar adds per K
+    // step instead of 64-bit multiplies per DMA issue)
     __device__ __forceinline__ void advance() {
         e0 = e1; ks0 = ks1;
         e1 = e2; ks1 = ks2;
-        if (++ks2 == KS) { ks2 = 0; ++e2; }
+        if (++ks2 == KS) {
+            ks2 = 0;
+            ++e2;
+            tile2 += (e2 == nt) ? -(long long)(nt - 1) * tile_bytes : tile_bytes;   // last entry = first tile again
+        }
+        if (++ksl2 == KS) ksl2 = 0;
+        a2 = tile2 + (size_t)ksl2 * SCAN_ROW_BYTES;
+        b2 = qbase + (size_t)ksl2 * SCAN_ROW_BYTES;
     }
 };
 
@@ -153,23 +169,23 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
     char* u1 = P.slot_of(s, 1);
     char* u2 = P.slot_of(s, 2);
     char* u3 = P.slot_of(s, 3);
-    const bool more2 = s + 2 < P.S;
-    const bool entry_start = P.ks0 == 0 && s > 0;
+    const bool more2 = s + 2 < P.S && !P.no_dma;
+    const bool entry_start = P.ks0 == 0 && s > 0 && !P.no_filter;
 
     // ================= slot 0: A^0 x B^0
-    read_b(bY, u1, P.ruB, P.cq);
+    if (!P.no_mma) read_b(bY, u1, P.ruB, P.cq);
     if (P.refresh_pending >= 0) {            // fetched during an earlier K step, retired by its slot-2 wait
-        refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.wave, fresh_lane());
+        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
         P.refresh_pending = -1;
     }
-    if (P.gshift >= 0 && P.e0 > 0 && (P.ks0 % P.refresh_every) == 0) {
+    if (P.gshift >= 0 && P.e0 > 0 && (P.ks0 % P.refresh_every) == 0 && !P.no_filter) {
         P.refresh_pending = P.refresh_ctr % NSLICE8;
         ++P.refresh_ctr;
         refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
     }
-    if (more2) issue_unit(P.a_src(P.e2, P.ks2), P.offA[0], P.offA[1], u0, P.wave);
+    if (more2) issue_unit(P.a2, P.offA[0], P.offA[1], u0, P.wave);
     if (P.ks0 == 0) {
-        if (s > 0) {
+        if (s > 0 && !P.no_filter) {
             // filter of the entry finished by the previous K step
             const int64_t row0 = (int64_t)P.tile_of(P.e0 - 1) * SCAN_BM;
             const int fl = fresh_lane();
@@ -185,7 +201,7 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfma_quad<0, 0>(acc, a, bX);
+    if (!P.no_mma) mfma_quad<0, 0>(acc, a, bX);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SQE_BARRIER();
 
@@ -201,27 +217,27 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (more2) issue_unit(P.b_src(P.ks2) + P.b1_off, P.offB[0], P.offB[1], u1, P.wave);
+    if (more2) issue_unit(P.b2 + P.b1_off, P.offB[0], P.offB[1], u1, P.wave);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_quad_refill<0, 2>(acc, a, bY, u2, true, P.ruA, P.cq);          // a <- A^1(s)
+    if (!P.no_mma) mfma_quad_refill<0, 2>(acc, a, bY, u2, true, P.ruA, P.cq);          // a <- A^1(s)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SQE_BARRIER();
 
     // ================= slot 2: A^1 x B^1; K step s+1 retired
-    read_b(bX, u3, P.ruB, P.cq);
-    if (more2) issue_unit(P.a_src(P.e2, P.ks2) + P.a1_off, P.offA[0], P.offA[1], u2, P.wave);
+    if (!P.no_mma) read_b(bX, u3, P.ruB, P.cq);
+    if (more2) issue_unit(P.a2 + P.a1_off, P.offA[0], P.offA[1], u2, P.wave);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_quad<4, 2>(acc, a, bY);
+    if (!P.no_mma) mfma_quad<4, 2>(acc, a, bY);
     if (more2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     SQE_BARRIER();
 
     // ================= slot 3: A^1 x B^0; fragments of K step s+1
     const bool more1 = s + 1 < P.S;
-    if (more1) read_b(bY, P.slot_of(s + 1, 3), P.ruB, P.cq);
-    if (more2) issue_unit(P.b_src(P.ks2), P.offB[0], P.offB[1], u3, P.wave);
+    if (more1 && !P.no_mma) read_b(bY, P.slot_of(s + 1, 3), P.ruB, P.cq);
+    if (more2) issue_unit(P.b2, P.offB[0], P.offB[1], u3, P.wave);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_quad_refill<4, 0>(acc, a, bX, P.slot_of(s + 1, 0), more1, P.ruA, P.cq);   // a <- A^0(s+1)
+    if (!P.no_mma) mfma_quad_refill<4, 0>(acc, a, bX, P.slot_of(s + 1, 0), more1, P.ruA, P.cq);   // a <- A^0(s+1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SQE_BARRIER();
 
@@ -256,15 +272,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     // entries: 0 = first tile (BOOT), 1..nt-1 = the other tiles, nt = the first tile again
     const int n_entries = P.nt > 0 ? P.nt + 1 : 0;
     P.S = n_entries * P.KS;
-    P.ld = (size_t)p.K * 2;
+    P.ldA = (size_t)p.db_pitch;
+    P.ldB = (size_t)p.q_pitch;
     P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift;
     P.refresh_every = P.KS >= NSLICE8 ? P.KS / NSLICE8 : 1;
+    P.rot = (logical * p.krot) % P.KS;
+    P.no_mma = (p.dbg & 1) != 0; P.no_dma = (p.dbg & 2) != 0; P.no_filter = (p.dbg & 4) != 0;
 
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
-    f.gstride = p.ngroups * GMAX_COLS;
-    P.gmax_group = p.gmax + ((size_t)q0 * p.ngroups + (chunk % p.ngroups)) * GMAX_COLS;
-    f.gmax_mine = const_cast<uint32_t*>(P.gmax_group) + chunk / p.ngroups;
+    f.gstride = p.ngroups * GMAX_COLS * 64;
+    P.gmax_group = p.gmax + ((size_t)(q0 / 64) * p.ngroups + (chunk % p.ngroups)) * (GMAX_COLS * 64);
+    f.gmax_mine = const_cast<uint32_t*>(P.gmax_group) + (chunk / p.ngroups) * 64;
     f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL8::OFF_THR_KEY);
     f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL8::OFF_THR_S);
     f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL8::OFF_CNT);
@@ -288,12 +307,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     for (int t = 0; t < 2; ++t) {
         const int ru = (P.wave + 8 * t) * 8 + (P.lane >> 3);      // unit row 0..127
         const int c = (P.lane & 7) ^ ((ru >> 1) & 7);             // source chunk (swizzle on the source)
-        P.offA[t] = (unsigned)(((ru >> 6) * 128 + (ru & 63)) * P.ld) + c * 16;
-        P.offB[t] = (unsigned)(((ru >> 5) * 64 + (ru & 31)) * P.ld) + c * 16;
+        P.offA[t] = (unsigned)(((ru >> 6) * 128 + (ru & 63)) * P.ldA) + c * 16;
+        P.offB[t] = (unsigned)(((ru >> 5) * 64 + (ru & 31)) * P.ldB) + c * 16;
     }
-    P.a1_off = (unsigned)(64 * P.ld);     // A^1 = A^0 + 64 rows
-    P.b1_off = (unsigned)(32 * P.ld);     // B^1 = B^0 + 32 queries
-    P.qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * P.ld;
+    P.a1_off = (unsigned)(64 * P.ldA);     // A^1 = A^0 + 64 rows
+    P.b1_off = (unsigned)(32 * P.ldB);     // B^1 = B^0 + 32 queries
+    P.qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * P.ldB;
     P.dbbase = reinterpret_cast<const char*>(p.db);
     P.ruA = P.wm * 64 + (P.lane & 15);
     P.ruB = P.wn * 32 + (P.lane & 15);
@@ -306,6 +325,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     if (P.ks2 == P.KS) { P.ks2 = 0; ++P.e2; }
     P.refresh_pending = -1;
     P.refresh_ctr = 0;
+    P.tile_bytes = (long long)SCAN_BM * (long long)P.ldA;
+    P.tile2 = P.dbbase + (size_t)P.tile_of(P.e2) * SCAN_BM * P.ldA;
+    P.ksl2 = P.kslice(P.ks2);
+    P.a2 = P.tile2 + (size_t)P.ksl2 * SCAN_ROW_BYTES;
+    P.b2 = P.qbase + (size_t)P.ksl2 * SCAN_ROW_BYTES;
 
     f32x4 acc[8][4];
     AFrag a;
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     }
 
     // ---- tail: filter of the last entry (the rescan of the first tile)
-    if (P.S > 0) {
+    if (P.S > 0 && !P.no_filter) {
         if (filter_tile<8, 4>(acc, f, (int64_t)P.tile_begin * SCAN_BM, P.wm * 128, P.wn * 64, P.lane))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

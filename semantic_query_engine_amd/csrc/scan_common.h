@@ -7,11 +7,13 @@
 //   * A row survives when its key exceeds the threshold.  The threshold is the maximum of
 //       - the LOCAL bound: the kp-th best key of this chunk so far (set by list compaction);
 //       - the GLOBAL bound: every chunk publishes its per-query maximum score to a small
-//         table gmax[query][group][64]; for 64 published maxima m_0..m_63 (64 distinct real
-//         rows) min over g-sized groups of max-in-group is a score that at least 64/g >= kp
-//         distinct rows reach, hence a lower bound of the final kp-th best score.  With all
-//         chunks streaming in parallel this bound tracks the whole index, not one chunk, so
-//         survivors become rare after the first few tiles.
+//         table gmax[query slice of 64][group][64 columns][64 queries]; for the 64 published
+//         maxima m_0..m_63 of a query (64 distinct real rows) min over g-sized groups of
+//         max-in-group is a score that at least 64/g >= kp distinct rows reach, hence a lower
+//         bound of the final kp-th best score.  With all chunks streaming in parallel this
+//         bound tracks the whole index, not one chunk, so survivors become rare after the
+//         first few tiles.  (Columns-major inside a slice: a lane owns a query and walks the
+//         64 columns with conflict-free LDS reads, no cross-lane traffic.)
 //   * The first tile of a chunk runs in BOOT mode: it only folds per-lane maxima into the
 //     chunk maximum (no appends, so no first-tile append storm); that tile is scanned again,
 //     normally, at the end of the chunk.
@@ -34,6 +36,8 @@ struct ScanKernelArgs {
     const bf16_t* q;
     int64_t n_rows;
     int K;
+    int db_pitch;        // bytes between DB rows of the scanned copy
+    int q_pitch;         // bytes between query rows
     int B;
     int b_pad;
     int n_tiles;
@@ -44,9 +48,11 @@ struct ScanKernelArgs {
     int trig;            // compaction trigger (kp <= trig <= CAND_CAP - SCAN_BM)
     int ngroups;         // chunk c publishes to gmax[q][c % ngroups][c / ngroups]
     int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
+    int krot;            // workgroup w walks K rotated by w * krot steps
+    int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter
     uint64_t* cand;
     int* cand_cnt;
-    uint32_t* gmax;      // [b_pad][ngroups][GMAX_COLS] orderable scores, 0 = nothing yet
+    uint32_t* gmax;      // [b_pad/64][ngroups][GMAX_COLS][64] orderable scores, 0 = nothing yet
 };
 
 // LDS block of the filter state for a query block of BN queries (after the staging area).
@@ -63,7 +69,7 @@ struct FilterLds {
 
 struct Filter {
     uint64_t* cand_base;   // this workgroup's lists: [BN][CAND_CAP]
-    uint32_t* gmax_mine;   // &gmax[q0][group][col]: this chunk's column, query stride = ngroups*64
+    uint32_t* gmax_mine;   // this chunk's column of slice 0 of the block: query q at [(q/64)*gstride + q%64]
     uint64_t* thr_key;
     float* thr_s;
     int* cnt;
@@ -73,7 +79,7 @@ struct Filter {
     int q_live;            // live queries in this block
     int trig;
     int per_wave;          // queries owned per wave (BN / 8)
-    int gstride;           // ngroups * GMAX_COLS (uint32 elements between consecutive queries)
+    int gstride;           // ngroups * GMAX_COLS * 64: uint32 elements between consecutive query slices
 };
 
 // host: kernel argument block from a plan (scan.hip)
@@ -178,7 +184,8 @@ __device__ __forceinline__ void filter_boot(const f32x4 (&acc)[FM][FN], const Fi
 __device__ __forceinline__ void publish_cmax(const Filter& f, int first_q, int per_wave, int lane) {
     if (lane < per_wave && first_q + lane < f.q_live) {
         const uint32_t m = f.cmax[first_q + lane];
-        if (m) store_sc1_u32(f.gmax_mine + (size_t)(first_q + lane) * f.gstride, m);
+        const int q = first_q + lane;
+        if (m) store_sc1_u32(f.gmax_mine + (size_t)(q >> 6) * f.gstride + (q & 63), m);
     }
 }
 
@@ -217,7 +224,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                                     if (slot + 1 >= f.trig) f.flags[qcol / f.per_wave] = 1;
                                     const uint32_t o = (uint32_t)(key >> 32);
                                     if (o > atomicMax(&f.cmax[qcol], o))
-                                        store_sc1_u32(f.gmax_mine + (size_t)qcol * f.gstride, o);
+                                        store_sc1_u32(f.gmax_mine + (size_t)(qcol >> 6) * f.gstride + (qcol & 63), o);
                                     stored = true;
                                 }
                             }
@@ -231,41 +238,43 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
 }
 
 // ---------------------------------------------------------------- global bound refresh
-// Issue the LDS-DMA fetch of the gmax rows of GSLICE_Q queries (slice `sl` of the block):
-// 16 pieces of 1 KiB (4 query rows of 256 B each), wave w issues pieces w and w + 8.
+// Issue the LDS-DMA fetch of one query slice of the table (64 columns x 64 queries x 4 B =
+// 16 KiB, contiguous): 16 pieces of 1 KiB, wave w issues pieces w and w + 8.
 __device__ __forceinline__ void refresh_issue(const uint32_t* gmax_block_group, int gstride, int sl,
                                               char* gstage, int wave, int lane) {
+    const char* src = reinterpret_cast<const char*>(gmax_block_group + (size_t)sl * gstride) + lane * 16;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int piece = wave + 8 * t;
-        const int qq = piece * 4 + (lane >> 4);                      // query within the slice
-        const char* src = reinterpret_cast<const char*>(gmax_block_group + (size_t)(sl * GSLICE_Q + qq) * gstride) +
-                          (lane & 15) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
                                          (__attribute__((address_space(3))) void*)(gstage + piece * 1024),
                                          16, 0, /*aux: sc1*/ 16);
     }
 }
 
-// After the fetch has landed: wave w folds queries w*8 .. w*8+7 of the slice.
-__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift,
-                                              int wave, int lane) {
-    const uint32_t* st = reinterpret_cast<const uint32_t*>(gstage);
-#pragma unroll
-    for (int t = 0; t < GSLICE_Q / SCAN_NWAVES; ++t) {
-        const int qq = wave * (GSLICE_Q / SCAN_NWAVES) + t;
-        uint32_t v = st[qq * GMAX_COLS + lane];
-        // max inside groups of 2^gshift neighbouring lanes, then min over all lanes
-        for (int d = 1; d < (1 << gshift); d <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
-        const int q = sl * GSLICE_Q + qq;
-        if (lane == 0 && v != 0u && q < f.q_live) {
-            const uint64_t gk = (uint64_t)v << 32;
-            if (gk > f.thr_key[q]) {
-                f.thr_key[q] = gk;
-                f.thr_s[q] = f32_from_orderable(v);
-            }
+// After the fetch has landed: ONE wave folds the slice, lane = query.  Walks the 64 columns
+// (conflict-free ds_read_b32, no cross-lane traffic): max inside groups of 2^gshift columns,
+// min over the groups.
+__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift, int lane) {
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(gstage) + lane;
+    uint32_t bound = 0xFFFFFFFFu;
+    if (gshift == 0) {
+#pragma unroll 16
+        for (int c = 0; c < GMAX_COLS; ++c) bound = min(bound, st[c * 64]);
+    } else if (gshift == 1) {
+#pragma unroll 8
+        for (int c = 0; c < GMAX_COLS; c += 2) bound = min(bound, max(st[c * 64], st[(c + 1) * 64]));
+    } else {
+#pragma unroll 4
+        for (int c = 0; c < GMAX_COLS; c += 4)
+            bound = min(bound, max(max(st[c * 64], st[(c + 1) * 64]), max(st[(c + 2) * 64], st[(c + 3) * 64])));
+    }
+    const int q = sl * GSLICE_Q + lane;
+    if (bound != 0u && q < f.q_live) {
+        const uint64_t gk = (uint64_t)bound << 32;
+        if (gk > f.thr_key[q]) {
+            f.thr_key[q] = gk;
+            f.thr_s[q] = f32_from_orderable(bound);
         }
     }
 }
