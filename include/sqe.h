@@ -33,6 +33,7 @@ typedef struct sqe_ctx sqe_ctx;
 typedef struct sqe_index sqe_index;
 typedef struct sqe_cache sqe_cache;
 typedef struct sqe_encoder sqe_encoder;
+typedef struct sqe_tokenizer sqe_tokenizer;
 
 enum {
     SQE_OK = 0,
@@ -155,10 +156,17 @@ void sqe_encoder_destroy(sqe_encoder* enc);
 int sqe_encoder_load_tensor(sqe_encoder* enc, const char* name, const float* data_host,
                             const int64_t* shape, int ndim);
 int sqe_encoder_finalize(sqe_encoder* enc);
-/* Host-only BERT WordPiece (lower-case, accent strip, punctuation/CJK split, greedy
- * longest match, [CLS]/[SEP], truncation to max_len).  vocab: one token per line. */
-int sqe_tokenizer_load(sqe_encoder* enc, const char* vocab_utf8, int64_t vocab_bytes);
-int sqe_tokenize(sqe_encoder* enc, const char* text_utf8, int max_len, int32_t* ids_out, int* len_out);
+/* Host-only BERT WordPiece (clean, CJK spacing, NFD + accent strip, lower-case, punctuation
+ * split, greedy longest match with "##" continuations, [CLS] ... [SEP], truncation to max_len
+ * ids): the tokenizer that ran inside Ollama for main.py:139-142.  Needs no GPU and no context.
+ * vocab_utf8: one token per line, line number = id (a local vocab.txt; nothing is fetched). */
+int sqe_tokenizer_create(const char* vocab_utf8, int64_t vocab_bytes, sqe_tokenizer** out);
+void sqe_tokenizer_destroy(sqe_tokenizer* tok);
+int sqe_tokenize(const sqe_tokenizer* tok, const char* text_utf8, int64_t text_bytes, int max_len,
+                 int32_t* ids_out, int* len_out);
+/* n texts -> ids_out [n, max_len] ([PAD] = 0 filled), lens_out [n]; multi-threaded for n >= 64. */
+int sqe_tokenize_batch(const sqe_tokenizer* tok, const char* const* texts, const int64_t* text_bytes, int n,
+                       int max_len, int32_t* ids_out, int32_t* lens_out);
 /* ids [B,S] int32 row-major (anything past lens[b] is ignored), lens [B];
  * out [B, hidden] fp32 = final-layer CLS row (no normalisation, as Ollama's
  * /api/embeddings output feeds main.py:315-316 and :59-64 un-normalised). */

@@ -64,8 +64,10 @@ SIGNATURES = {
     "sqe_encoder_destroy": (None, [C.c_void_p]),
     "sqe_encoder_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int]),
     "sqe_encoder_finalize": (C.c_int, [C.c_void_p]),
-    "sqe_tokenizer_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
-    "sqe_tokenize": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_i32_p, c_i32_p]),
+    "sqe_tokenizer_create": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sqe_tokenizer_destroy": (None, [C.c_void_p]),
+    "sqe_tokenize": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.c_int, c_i32_p, c_i32_p]),
+    "sqe_tokenize_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), c_i64_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sqe_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sqe_encode_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sqe_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

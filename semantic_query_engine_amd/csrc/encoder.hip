@@ -15,12 +15,6 @@ int sqe_encoder_load_tensor(sqe_encoder*, const char*, const float*, const int64
     return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
 }
 int sqe_encoder_finalize(sqe_encoder*) { return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build"); }
-int sqe_tokenizer_load(sqe_encoder*, const char*, int64_t) {
-    return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
-}
-int sqe_tokenize(sqe_encoder*, const char*, int, int32_t*, int*) {
-    return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
-}
 int sqe_encode(sqe_encoder*, const int32_t*, const int32_t*, int, int, float*) {
     return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
 }

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     f.q_live = min(BN, p.B - q0);
     f.trig = p.trig;
     f.per_wave = PER_WAVE;
+    f.dbg_no_slow = (p.dbg & 16) != 0;
     for (int i = tid; i < BN; i += THREADS) {
         const bool live = (q0 + i) < p.B;
         f.thr_key[i] = live ? 0ull : ~0ull;

@@ -178,7 +178,8 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
         if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
         P.refresh_pending = -1;
     }
-    if (P.gshift >= 0 && P.e0 > 0 && (P.ks0 % P.refresh_every) == 0 && !P.no_filter) {
+    // every slice once per tile while the bound is still moving fast, one slice per tile later
+    if (P.gshift >= 0 && P.e0 > 0 && (P.ks0 % P.refresh_every) == 0 && (P.e0 <= 32 || P.ks0 == 0) && !P.no_filter) {
         P.refresh_pending = P.refresh_ctr % NSLICE8;
         ++P.refresh_ctr;
         refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
@@ -191,8 +192,10 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
             const int fl = fresh_lane();
             if (P.e0 - 1 == 0) {
                 filter_boot<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl);
-            } else if (filter_tile<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // publish appended keys
+            } else {
+                // appended keys are NOT drained here: a vmcnt(0) would wait for every DMA piece in
+                // flight.  They only have to be visible if a list is compacted, which slot 1 checks.
+                filter_tile<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl);
             }
         }
 #pragma unroll
@@ -210,10 +213,20 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
         // every wave's filter stores for the previous entry are published (drained before the barrier)
         if (P.e0 - 1 == 0) {
             publish_cmax(f, P.wave * 32, 32, fresh_lane());
-        } else if (__builtin_amdgcn_readfirstlane(f.flags[P.wave]) != 0) {
+        } else {
+            // flags[w] != 0: a list owned by wave w reached the compaction trigger.  Every wave reads
+            // the same eight words after the barrier, so the branch (and its barrier) is uniform.
             const int fl = fresh_lane();
-            if (fl == 0) f.flags[P.wave] = 0;
-            compact_owned(f, P.wave * 32, 32, P.trig, P.kp, fl);
+            const int any_flag = __builtin_amdgcn_readfirstlane(__any(f.flags[fl & 7] != 0));
+            if (any_flag) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my appended keys are in memory
+                SQE_BARRIER();
+                if (__builtin_amdgcn_readfirstlane(f.flags[P.wave]) != 0)
+                    compact_owned(f, P.wave * 32, 32, P.trig, P.kp, fl);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                SQE_BARRIER();                                                 // sweeps done before flags are cleared
+                if (fl == 0) f.flags[P.wave] = 0;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -278,6 +291,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     P.refresh_every = P.KS >= NSLICE8 ? P.KS / NSLICE8 : 1;
     P.rot = (logical * p.krot) % P.KS;
     P.no_mma = (p.dbg & 1) != 0; P.no_dma = (p.dbg & 2) != 0; P.no_filter = (p.dbg & 4) != 0;
+    if (p.dbg & 8) P.gshift = -1;
 
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     f.q_live = min(BN8, p.B - q0);
     f.trig = p.trig;
     f.per_wave = 32;
+    f.dbg_no_slow = (p.dbg & 16) != 0;
     for (int i = tid; i < BN8; i += SCAN_THREADS) {
         const bool live = (q0 + i) < p.B;
         f.thr_key[i] = live ? 0ull : ~0ull;

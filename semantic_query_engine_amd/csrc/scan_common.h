@@ -49,7 +49,8 @@ struct ScanKernelArgs {
     int ngroups;         // chunk c publishes to gmax[q][c % ngroups][c / ngroups]
     int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
     int krot;            // workgroup w walks K rotated by w * krot steps
-    int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter
+    int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter,
+                         //   8 = no global-bound refresh, 16 = filter fast path only
     uint64_t* cand;
     int* cand_cnt;
     uint32_t* gmax;      // [b_pad/64][ngroups][GMAX_COLS][64] orderable scores, 0 = nothing yet
@@ -80,6 +81,7 @@ struct Filter {
     int trig;
     int per_wave;          // queries owned per wave (BN / 8)
     int gstride;           // ngroups * GMAX_COLS * 64: uint32 elements between consecutive query slices
+    bool dbg_no_slow;      // timing experiments only: pretend no row survives
 };
 
 // host: kernel argument block from a plan (scan.hip)
@@ -207,7 +209,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
             fmx[i] = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
             mx = fmaxf(mx, fmx[i]);
         }
-        if (__any(mx >= thr)) {                     // rare: some lane of this column group has a survivor
+        if (__any(mx >= thr) && !f.dbg_no_slow) {    // rare: some lane of this column group has a survivor
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (__any(fmx[i] >= thr)) {
