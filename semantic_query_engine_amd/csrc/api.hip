@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of include/sqe.h: context, flat vector index, search pipeline,
 // cache scan and stats.  No C++ types or exceptions cross this boundary.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -137,6 +138,7 @@ struct sqe_index {
     DevBuf cand;                   // [n_chunks, b_pad, CAND_CAP] u64
     DevBuf cand_cnt;               // [n_chunks, b_pad] int
     DevBuf gmax;                   // [b_pad, ngroups, 64] u32 chunk maxima (global bound table)
+    DevBuf dbg;                    // 8 x u64 debug counters (SQE_DBG bit 32)
 };
 
 struct sqe_cache {
@@ -435,6 +437,15 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
         a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
         a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
+        a.dbg_counters = nullptr;
+        {
+            static const bool want = [] { const char* e = getenv("SQE_DBG"); return e && (atoi(e) & 32); }();
+            if (want) {
+                SQE_TRY(idx->dbg.ensure(64));
+                SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 64, c->stream));
+                a.dbg_counters = idx->dbg.as<unsigned long long>();
+            }
+        }
         SQE_TRY(launch_scan_bf16(plan, a, c->stream));
     } else {
         SQE_HIP(hipMemsetAsync(idx->cand_cnt.p, 0, (size_t)plan.n_chunks * plan.b_pad * 4, c->stream));
@@ -447,6 +458,12 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         s.master = idx->master; s.qn = idx->qn.as<float>(); s.K = K; s.B = B; s.k = k;
         s.cos_out = cos_out_dev; s.id_out = id_out_dev; s.id_base = idx->id_base;
         SQE_TRY(launch_select_rescore(s, c->stream));
+    }
+    if (idx->dbg.p) {
+        unsigned long long h[8];
+        SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 64, hipMemcpyDeviceToHost, c->stream));
+        SQE_HIP(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[sqe dbg] appends=%llu slow_path_entries=%llu compactions=%llu\n", h[0], h[1], h[2]);
     }
     c->search_calls++;
     c->last_scan_rows = idx->n;

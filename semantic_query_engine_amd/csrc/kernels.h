@@ -46,6 +46,7 @@ struct ScanArgs {
     uint64_t* cand;       // [n_chunks, b_pad, CAND_CAP] candidate keys
     int* cand_cnt;        // [n_chunks, b_pad]
     uint32_t* gmax;       // [b_pad, ngroups, GMAX_COLS], zeroed before the launch
+    unsigned long long* dbg_counters;   // null unless SQE_DBG has bit 32
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless

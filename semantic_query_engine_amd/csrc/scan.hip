@@ -114,6 +114,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     f.trig = p.trig;
     f.per_wave = PER_WAVE;
     f.dbg_no_slow = (p.dbg & 16) != 0;
+    f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
     for (int i = tid; i < BN; i += THREADS) {
         const bool live = (q0 + i) < p.B;
         f.thr_key[i] = live ? 0ull : ~0ull;
@@ -163,12 +164,17 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             stage_tile<BM>(dbbase + (size_t)tile_of(nentry) * BM * ldA + (size_t)kslice(nks) * ROW_BYTES, ldA, nxt, wave, lane);
             stage_tile<BN>(qbase + (size_t)kslice(nks) * ROW_BYTES, ldB, nxt + BM * ROW_BYTES, wave, lane);
         }
-        if (ks == 0) {
-            if (entry > 0 && p.gshift >= 0) {       // one slice of the global bound per tile
+        {
+            // Bound refresh schedule: entry 1 fetches every slice back to back from K step KS/4 on
+            // (after every chunk has published its boot maxima); later one slice per tile.
+            const bool want = entry == 1 ? (ks >= KS / 4 && refresh_ctr < NSLICE) : (entry > 1 && ks == 0);
+            if (want && p.gshift >= 0) {
                 refresh_pending = refresh_ctr % NSLICE;
                 ++refresh_ctr;
                 refresh_issue(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
             }
+        }
+        if (ks == 0) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -251,7 +257,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
         k.krot = krot;
         k.dbg = dbg;
     }
-    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax; k.dbg_counters = a.dbg_counters;
     return k;
 }
 

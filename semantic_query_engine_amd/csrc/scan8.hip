@@ -178,8 +178,13 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
         if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
         P.refresh_pending = -1;
     }
-    // every slice once per tile while the bound is still moving fast, one slice per tile later
-    if (P.gshift >= 0 && P.e0 > 0 && (P.ks0 % P.refresh_every) == 0 && (P.e0 <= 32 || P.ks0 == 0) && !P.no_filter) {
+    // Bound refresh schedule.  Entry 1 (the first filtered tile): all slices back to back, but
+    // only from K step KS/4 on, when every chunk has published its boot maxima (fetching earlier
+    // would read an empty table and leave those queries without a threshold for a whole tile).
+    // Then every slice once per tile while the bound still moves fast, one slice per tile later.
+    const bool want_refresh = P.e0 == 1 ? (P.ks0 >= P.KS / 4 && P.refresh_ctr < NSLICE8)
+                                        : (P.e0 <= 32 ? (P.ks0 % P.refresh_every) == 0 : P.ks0 == 0);
+    if (P.gshift >= 0 && P.e0 > 0 && want_refresh && !P.no_filter) {
         P.refresh_pending = P.refresh_ctr % NSLICE8;
         ++P.refresh_ctr;
         refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     f.trig = p.trig;
     f.per_wave = 32;
     f.dbg_no_slow = (p.dbg & 16) != 0;
+    f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
     for (int i = tid; i < BN8; i += SCAN_THREADS) {
         const bool live = (q0 + i) < p.B;
         f.thr_key[i] = live ? 0ull : ~0ull;

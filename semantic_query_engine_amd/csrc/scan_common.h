@@ -54,6 +54,7 @@ struct ScanKernelArgs {
     uint64_t* cand;
     int* cand_cnt;
     uint32_t* gmax;      // [b_pad/64][ngroups][GMAX_COLS][64] orderable scores, 0 = nothing yet
+    unsigned long long* dbg_counters;   // [8] or null: 0 appends, 1 slow-path wave entries, 2 compactions
 };
 
 // LDS block of the filter state for a query block of BN queries (after the staging area).
@@ -82,6 +83,7 @@ struct Filter {
     int per_wave;          // queries owned per wave (BN / 8)
     int gstride;           // ngroups * GMAX_COLS * 64: uint32 elements between consecutive query slices
     bool dbg_no_slow;      // timing experiments only: pretend no row survives
+    unsigned long long* dbg_counters;
 };
 
 // host: kernel argument block from a plan (scan.hip)
@@ -151,6 +153,7 @@ __device__ __forceinline__ void compact_owned(const Filter& f, int first_q, int 
     while (mask) {
         const int bq = first_q + (int)__builtin_ctzll(mask);
         mask &= mask - 1;
+        if (f.dbg_counters && lane == 0) atomicAdd(&f.dbg_counters[2], 1ull);
         compact_list(f.cand_base + (size_t)bq * CAND_CAP, f.cnt[bq], kp, lane, &f.cnt[bq], &f.thr_s[bq],
                      &f.thr_key[bq]);
     }
@@ -210,6 +213,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
             mx = fmaxf(mx, fmx[i]);
         }
         if (__any(mx >= thr) && !f.dbg_no_slow) {    // rare: some lane of this column group has a survivor
+            if (f.dbg_counters && lane == 0) atomicAdd(&f.dbg_counters[1], 1ull);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (__any(fmx[i] >= thr)) {
@@ -222,6 +226,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                                 const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
                                 if (key > f.thr_key[qcol]) {
                                     const int slot = atomicAdd(&f.cnt[qcol], 1);
+                                    if (f.dbg_counters) atomicAdd(&f.dbg_counters[0], 1ull);
                                     f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;
                                     if (slot + 1 >= f.trig) f.flags[qcol / f.per_wave] = 1;
                                     const uint32_t o = (uint32_t)(key >> 32);
