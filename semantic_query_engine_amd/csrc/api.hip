@@ -196,6 +196,14 @@ int auto_kp(const sqe_index* idx, int k) {
 
 }  // namespace
 
+// accessors used by encoder.hip (sqe_ctx is defined in this file only)
+namespace sqe {
+int ctx_cu_count(sqe_ctx* ctx) { return ctx->cu_count; }
+int ctx_device(sqe_ctx* ctx) { return ctx->device; }
+void ctx_lock(sqe_ctx* ctx) { ctx->mu.lock(); }
+void ctx_unlock(sqe_ctx* ctx) { ctx->mu.unlock(); }
+}  // namespace sqe
+
 // ================================================================ library / context
 extern "C" {
 

@@ -1,25 +1,660 @@
-// encoder.hip -- BERT-large encoder entry points (ollama_embed_text stand-in, main.py:134-145).
-// Placeholder until the HIP encoder lands: every entry point reports UNSUPPORTED loudly.
+// encoder.hip -- BERT encoder (mxbai-embed-large = BERT-large: 24 x {MHA 16x64, FFN 4096}, post-LN,
+// erf-GELU, CLS pooling) behind sqe_encode*: stands where Ollama's /api/embeddings stood for
+// ollama_embed_text (main.py:134-145).  bf16 weights and activations, fp32 MFMA accumulation,
+// fp32 softmax / LayerNorm / residual sums.
+//
+// Kernels (gfx950, wave64):
+//   E1 embed_ln_kernel      word + position + type embedding, LayerNorm            (HBM stream)
+//   E2/E4/E5/E6 gemm_bf16_kernel<FM,FN,EPI>  Y = X W^T + b on v_mfma_f32_16x16x32_bf16, both
+//                           operands staged global -> LDS by global_load_lds in full 128-B lines
+//                           (XOR chunk swizzle on the source address and on the ds_read_b128
+//                           address), double buffered; epilogues: bias | bias + erf-GELU |
+//                           bias + residual (fp32 out, feeds LayerNorm)           (MFMA-bound)
+//   E3 attention_kernel     flash-style per (sequence, head, 64 query rows): S^T = K Q^T so the
+//                           probabilities land in registers exactly as the A operand of the P V
+//                           MFMA; V fragments by ds_read_b64_tr_b16; online softmax in fp32
+//   layernorm_kernel        fp32 row -> bf16 row;  E7 pool_ln_kernel: LayerNorm of the CLS rows -> fp32
+//
+// Token layout: padded [B, S] (row = b * S + s); keys at positions >= lens[b] are masked, padded
+// query rows compute values nobody reads.  Activation buffers are padded to a multiple of the
+// GEMM token tile.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
 #include "kernels.h"
+
+namespace sqe {
+
+namespace {
+
+constexpr int ROWB = 128;   // bytes per tile row per 64-wide bf16 K step
+
+// ------------------------------------------------------------------ staging helpers
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_rows(const char* gbase, size_t ld_bytes, char* lds, int wave, int lane) {
+    constexpr int NINSTR = ROWS / 8;          // one 1-KiB wave-instruction per 8 rows
+    constexpr int ITERS = (NINSTR + NW - 1) / NW;
+    const int r_local = lane >> 3;
+    const int cprime = lane & 7;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int g = it * NW + wave;
+        if (NINSTR % NW == 0 || g < NINSTR) {
+            const int r = g * 8 + r_local;
+            const int c = cprime ^ ((r >> 1) & 7);
+            const char* src = gbase + (size_t)r * ld_bytes + c * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + g * 1024), 16, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ bf16x8 frag(const char* tile, int r, int c) {
+    return *reinterpret_cast<const bf16x8*>(tile + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4));
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+
+// ------------------------------------------------------------------ GEMM
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+struct GemmArgs {
+    const bf16_t* W;      // [N, K] row-major (torch Linear weight)
+    const bf16_t* X;      // [T_pad, K]
+    const float* bias;    // [N]
+    const bf16_t* resid;  // [T_pad, N] (EPI_RESID)
+    void* out;            // bf16 [T_pad, N] or fp32 [T_pad, N] (EPI_RESID)
+    int N, K, T;          // T = valid token rows
+    int n_tiles;
+};
+
+// Block tile: (2*FM*16) output features x (4*FN*16) tokens, 8 waves as 2 (features) x 4 (tokens).
+// MFMA A operand = W rows, B operand = X rows, so a lane holds 4 CONSECUTIVE features of one
+// token per fragment: acc[i][j][r] = Y[t0 + j*16 + (lane&15)][n0 + i*16 + (lane>>4)*4 + r].
+template <int FM, int FN, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int BNW = 2 * FM * 16, BT = 4 * FN * 16;
+    constexpr int STAGE = (BNW + BT) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nt = blockIdx.x % p.n_tiles, tt = blockIdx.x / p.n_tiles;
+    const int n0 = nt * BNW, t0 = tt * BT;
+    const size_t ld = (size_t)p.K * 2;
+    const char* wbase = reinterpret_cast<const char*>(p.W) + (size_t)n0 * ld;
+    const char* xbase = reinterpret_cast<const char*>(p.X) + (size_t)t0 * ld;
+    const int KS = p.K / 64;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_rows<BNW, 8>(wbase, ld, smem, wave, lane);
+    stage_rows<BT, 8>(xbase, ld, smem + BNW * ROWB, wave, lane);
+    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+        const char* cur = smem + (ks & 1) * STAGE;
+        if (ks + 1 < KS) {
+            char* nxt = smem + ((ks + 1) & 1) * STAGE;
+            stage_rows<BNW, 8>(wbase + (size_t)(ks + 1) * ROWB, ld, nxt, wave, lane);
+            stage_rows<BT, 8>(xbase + (size_t)(ks + 1) * ROWB, ld, nxt + BNW * ROWB, wave, lane);
+        }
+        const char* tA = cur;
+        const char* tB = cur + BNW * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[FM], b[FN];
+            const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = frag(tA, wm * (FM * 16) + i * 16 + (lane & 15), c);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = frag(tB, wn * (FN * 16) + j * 16 + (lane & 15), c);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int n = n0 + wm * (FM * 16) + i * 16 + (lane >> 4) * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int t = t0 + wn * (FN * 16) + j * 16 + (lane & 15);
+            if (t >= p.T) continue;
+            float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+            const size_t o = (size_t)t * p.N + n;
+            if (EPI == EPI_RESID) {
+                const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o);
+                v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
+                v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v0, v1, v2, v3);
+            } else {
+                if (EPI == EPI_GELU) {
+                    v0 = 0.5f * v0 * (1.0f + erff(v0 * 0.70710678118654752f));
+                    v1 = 0.5f * v1 * (1.0f + erff(v1 * 0.70710678118654752f));
+                    v2 = 0.5f * v2 * (1.0f + erff(v2 * 0.70710678118654752f));
+                    v3 = 0.5f * v3 * (1.0f + erff(v3 * 0.70710678118654752f));
+                }
+                uint2 w2;
+                w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
+            }
+        }
+    }
+}
+
+template <int FM, int FN, int EPI>
+int launch_gemm_cfg(const GemmArgs& a, int t_pad, hipStream_t stream) {
+    constexpr int BNW = 2 * FM * 16, BT = 4 * FN * 16;
+    constexpr int LDS = 2 * (BNW + BT) * ROWB;
+    GemmArgs p = a;
+    p.n_tiles = a.N / BNW;
+    auto kern = gemm_bf16_kernel<FM, FN, EPI>;
+    static bool attr = false;
+    if (!attr) {
+        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.n_tiles * (t_pad / BT)), dim3(512), LDS, stream, p);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+// 256x256 tiles when there are enough tokens to fill the chip with them, 128x128 otherwise
+template <int EPI>
+int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream) {
+    if (a.N % 128 != 0 || a.K % 64 != 0) return fail(SQE_ERR_INVALID, "encoder gemm: N % 128 or K % 64");
+    const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
+    if (big) return launch_gemm_cfg<8, 4, EPI>(a, t_pad, stream);
+    return launch_gemm_cfg<4, 2, EPI>(a, t_pad, stream);
+}
+
+// ------------------------------------------------------------------ LayerNorm family
+// one wave per row; H % 4 == 0; two passes over registers-or-cache (row <= 16 KiB)
+__device__ __forceinline__ void ln_stats(const float* row, int H, int lane, float& mean, float& rstd, float eps) {
+    float s = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        s += v.x + v.y + v.z + v.w;
+    }
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += a * a + b * b + c * c + d * d;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ g,
+                                                        const float* __restrict__ b, bf16_t* __restrict__ out,
+                                                        int T, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float* x = in + (size_t)row * H;
+    float mean, rstd;
+    ln_stats(x, H, lane, mean, rstd, eps);
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i);
+        const float4 bb = *reinterpret_cast<const float4*>(b + i);
+        uint2 w;
+        w.x = (uint32_t)f32_to_bf16((v.x - mean) * rstd * gg.x + bb.x) | ((uint32_t)f32_to_bf16((v.y - mean) * rstd * gg.y + bb.y) << 16);
+        w.y = (uint32_t)f32_to_bf16((v.z - mean) * rstd * gg.z + bb.z) | ((uint32_t)f32_to_bf16((v.w - mean) * rstd * gg.w + bb.w) << 16);
+        *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = w;
+    }
+}
+
+// E7: LayerNorm of the CLS row of every sequence, fp32 out [B, H]
+__global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ in, const float* __restrict__ g,
+                                                      const float* __restrict__ b, float* __restrict__ out,
+                                                      int B, int S, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= B) return;
+    const float* x = in + (size_t)seq * S * H;
+    float mean, rstd;
+    ln_stats(x, H, lane, mean, rstd, eps);
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i);
+        const float4 bb = *reinterpret_cast<const float4*>(b + i);
+        *reinterpret_cast<float4*>(out + (size_t)seq * H + i) =
+            make_float4((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
+                        (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+    }
+}
+
+// E1: x = LN(word[id] + pos[s] + type[0]); the fp32 sum goes through `scratch` (one row per wave slot)
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, const bf16_t* __restrict__ word,
+                                                       const bf16_t* __restrict__ pos, const bf16_t* __restrict__ type,
+                                                       const float* __restrict__ g, const float* __restrict__ b,
+                                                       float* __restrict__ scratch, bf16_t* __restrict__ out,
+                                                       int T, int S, int H, int vocab, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int s = row % S;
+    float* tmp = scratch + (size_t)row * H;
+    for (int i = lane * 4; i < H; i += 256) {
+        const uint2 w = *reinterpret_cast<const uint2*>(word + (size_t)id * H + i);
+        const uint2 p = *reinterpret_cast<const uint2*>(pos + (size_t)s * H + i);
+        const uint2 t = *reinterpret_cast<const uint2*>(type + i);
+        float4 v;
+        v.x = bf16_to_f32((bf16_t)(w.x & 0xffff)) + bf16_to_f32((bf16_t)(p.x & 0xffff)) + bf16_to_f32((bf16_t)(t.x & 0xffff));
+        v.y = bf16_to_f32((bf16_t)(w.x >> 16)) + bf16_to_f32((bf16_t)(p.x >> 16)) + bf16_to_f32((bf16_t)(t.x >> 16));
+        v.z = bf16_to_f32((bf16_t)(w.y & 0xffff)) + bf16_to_f32((bf16_t)(p.y & 0xffff)) + bf16_to_f32((bf16_t)(t.y & 0xffff));
+        v.w = bf16_to_f32((bf16_t)(w.y >> 16)) + bf16_to_f32((bf16_t)(p.y >> 16)) + bf16_to_f32((bf16_t)(t.y >> 16));
+        *reinterpret_cast<float4*>(tmp + i) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    float mean, rstd;
+    ln_stats(tmp, H, lane, mean, rstd, eps);
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(tmp + i);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i);
+        const float4 bb = *reinterpret_cast<const float4*>(b + i);
+        uint2 w;
+        w.x = (uint32_t)f32_to_bf16((v.x - mean) * rstd * gg.x + bb.x) | ((uint32_t)f32_to_bf16((v.y - mean) * rstd * gg.y + bb.y) << 16);
+        w.y = (uint32_t)f32_to_bf16((v.z - mean) * rstd * gg.z + bb.z) | ((uint32_t)f32_to_bf16((v.w - mean) * rstd * gg.w + bb.w) << 16);
+        *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = w;
+    }
+}
+
+// ------------------------------------------------------------------ attention (head_dim = 64)
+// grid = B * heads * ceil(S / 64); 256 threads = 4 waves x 16 query rows.
+__device__ __forceinline__ uint2 lds_tr_b64(const char* addr) {
+    uint2 v;
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)addr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens,
+                                                        bf16_t* __restrict__ ctx, int S, int H, int heads) {
+    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sV[64 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qblocks = (S + 63) / 64;
+    const int qb = blockIdx.x % qblocks;
+    const int head = (blockIdx.x / qblocks) % heads;
+    const int seq = blockIdx.x / (qblocks * heads);
+    const int len = min(lens[seq], S);
+    if (qb * 64 >= len) return;                      // only padded query rows here
+    const int g = lane >> 4, c = lane & 15;
+    const size_t ld = (size_t)3 * H * 2;             // bytes per token row of qkv
+    const char* base = reinterpret_cast<const char*>(qkv) + (size_t)seq * S * ld + (size_t)head * 64 * 2;
+
+    // Q^T fragments of this wave's 16 query rows (B operand: lane (g,c) holds Q[q = c][d = kk*32 + g*8 ..+8))
+    const int q_row = qb * 64 + wave * 16 + c;
+    bf16x8 qf[2];
+    {
+        const int qr = q_row < S ? q_row : S - 1;
+        const char* qp = base + (size_t)qr * ld;
+        qf[0] = *reinterpret_cast<const bf16x8*>(qp + (0 * 32 + g * 8) * 2);
+        qf[1] = *reinterpret_cast<const bf16x8*>(qp + (1 * 32 + g * 8) * 2);
+    }
+    float m = -INFINITY, l = 0.f;                    // running max / sum of query row c
+    f32x4 o[4];                                      // O: col = d (dj*16 + c), row = query g*4 + r
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj) o[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kv0 = 0; kv0 < len; kv0 += 64) {
+        __syncthreads();                              // previous tile fully consumed
+        stage_rows<64, 4>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sK, wave, lane);       // K part
+        stage_rows<64, 4>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sV, wave, lane);   // V part
+        __syncthreads();                              // vmcnt(0) + barrier
+        // S^T[key][q] = sum_d K[key][d] Q[q][d]
+        f32x4 st[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            st[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(sK, kf * 16 + c, kk * 4 + g), qf[kk], st[kf], 0, 0, 0);
+        }
+        // scale, mask, online softmax for query row c (keys: kf*16 + g*4 + r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + kf * 16 + g * 4 + r;
+                const float s = key < len ? st[kf][r] * 0.125f : -INFINITY;
+                st[kf][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);            // finite: key kv0 < len is never masked
+        const float alpha = __expf(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(st[kf][r] - m_new);
+                st[kf][r] = pv;
+                psum += pv;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = m_new;
+        // rescale O rows (query g*4 + r) by that query's alpha (held by lane q = g*4 + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a_q = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) o[dj][r] *= a_q;
+        }
+        // O += P V : A operand = P straight from the S^T accumulators (k slot j of lane group g
+        // = key 16*(2*kk2 + (j>>2)) + 4*g + (j&3)); B operand = V by transposed LDS reads
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            bf16x8 pa;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16_t hb = f32_to_bf16(st[2 * kk2 + (j >> 2)][j & 3]);
+                pa[j] = __builtin_bit_cast(__bf16, hb);
+            }
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) {
+                // lane (g, c = 4*qq + pp) supplies row qq of each 4-key block, columns dj*16 + 4*pp ..
+                const int qq = c >> 2, pp = c & 3;
+                const int chunk = dj * 2 + (pp >> 1);
+                uint2 lo, hi;
+                {
+                    const int key = 16 * (2 * kk2) + 4 * g + qq;
+                    lo = lds_tr_b64(sV + key * ROWB + ((chunk ^ ((key >> 1) & 7)) << 4) + 8 * (pp & 1));
+                }
+                {
+                    const int key = 16 * (2 * kk2 + 1) + 4 * g + qq;
+                    hi = lds_tr_b64(sV + key * ROWB + ((chunk ^ ((key >> 1) & 7)) << 4) + 8 * (pp & 1));
+                }
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                const u32x4 packed = {lo.x, lo.y, hi.x, hi.y};
+                const bf16x8 vb = __builtin_bit_cast(bf16x8, packed);
+                o[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dj], 0, 0, 0);
+            }
+        }
+    }
+    // normalise and store: O[q = g*4 + r][d = dj*16 + c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float l_q = __shfl(l, g * 4 + r, 64);
+        const int q = qb * 64 + wave * 16 + g * 4 + r;
+        if (q < len) {
+            bf16_t* dst = ctx + ((size_t)seq * S + q) * H + head * 64;
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) dst[dj * 16 + c] = f32_to_bf16(o[dj][r] / l_q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct DevMem {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (n <= bytes) return SQE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return fail(SQE_ERR_OOM, std::string("encoder hipMalloc: ") + hipGetErrorString(e));
+        bytes = n;
+        return SQE_OK;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+bf16_t host_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+}  // namespace
+}  // namespace sqe
 
 using namespace sqe;
 
+struct sqe_layer {
+    DevMem w_qkv, b_qkv, w_o, b_o, ln1_g, ln1_b, w_1, b_1, w_2, b_2, ln2_g, ln2_b;
+};
+
+struct sqe_encoder {
+    sqe_ctx* ctx = nullptr;
+    sqe_bert_cfg cfg;
+    DevMem word, pos, type, emb_g, emb_b;
+    std::vector<std::unique_ptr<sqe_layer>> layers;
+    std::map<std::string, bool> loaded;
+    bool finalized = false;
+    // workspace
+    DevMem x, x1, qkv, att, hbuf, pre, ids, lens, out;
+    int t_cap = 0;
+};
+
+// sqe_ctx internals needed here (defined in api.hip)
+extern "C" void* sqe_stream(sqe_ctx* ctx);
+namespace sqe { int ctx_cu_count(sqe_ctx* ctx); int ctx_device(sqe_ctx* ctx); void ctx_lock(sqe_ctx*); void ctx_unlock(sqe_ctx*); }
+
+namespace {
+
+struct CtxGuard {
+    sqe_ctx* c;
+    explicit CtxGuard(sqe_ctx* ctx) : c(ctx) { ctx_lock(c); (void)hipSetDevice(ctx_device(c)); }
+    ~CtxGuard() { ctx_unlock(c); }
+};
+
+int upload(DevMem& dst, const float* src, size_t n, bool as_bf16, size_t offset_elems, size_t total_elems, hipStream_t st) {
+    SQE_TRY(dst.alloc(total_elems * (as_bf16 ? 2 : 4)));
+    if (as_bf16) {
+        std::vector<bf16_t> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = host_bf16(src[i]);
+        SQE_HIP(hipMemcpyAsync(dst.as<bf16_t>() + offset_elems, tmp.data(), n * 2, hipMemcpyHostToDevice, st));
+        SQE_HIP(hipStreamSynchronize(st));
+    } else {
+        SQE_HIP(hipMemcpyAsync(dst.as<float>() + offset_elems, src, n * 4, hipMemcpyHostToDevice, st));
+        SQE_HIP(hipStreamSynchronize(st));
+    }
+    return SQE_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
-int sqe_encoder_create(sqe_ctx*, const sqe_bert_cfg*, sqe_encoder** out) {
-    if (out) *out = nullptr;
-    return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
+int sqe_encoder_create(sqe_ctx* ctx, const sqe_bert_cfg* cfg, sqe_encoder** out) {
+    if (!ctx || !cfg || !out) return fail(SQE_ERR_INVALID, "sqe_encoder_create: null argument");
+    *out = nullptr;
+    if (cfg->hidden % 128 != 0 || cfg->inter % 128 != 0 || cfg->heads <= 0 || cfg->hidden / cfg->heads != 64 ||
+        cfg->layers <= 0 || cfg->max_pos <= 0 || cfg->vocab_size <= 0)
+        return fail(SQE_ERR_INVALID, "sqe_encoder_create: need hidden % 128 == 0, inter % 128 == 0, head_dim == 64");
+    std::unique_ptr<sqe_encoder> e(new (std::nothrow) sqe_encoder);
+    if (!e) return fail(SQE_ERR_OOM, "sqe_encoder_create: host allocation failed");
+    e->ctx = ctx;
+    e->cfg = *cfg;
+    for (int l = 0; l < cfg->layers; ++l) e->layers.emplace_back(new sqe_layer);
+    *out = e.release();
+    return SQE_OK;
 }
-void sqe_encoder_destroy(sqe_encoder*) {}
-int sqe_encoder_load_tensor(sqe_encoder*, const char*, const float*, const int64_t*, int) {
-    return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
+
+void sqe_encoder_destroy(sqe_encoder* enc) {
+    if (!enc) return;
+    {
+        CtxGuard g(enc->ctx);
+        (void)hipStreamSynchronize((hipStream_t)sqe_stream(enc->ctx));
+    }
+    delete enc;
 }
-int sqe_encoder_finalize(sqe_encoder*) { return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build"); }
-int sqe_encode(sqe_encoder*, const int32_t*, const int32_t*, int, int, float*) {
-    return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
+
+int sqe_encoder_load_tensor(sqe_encoder* enc, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+    if (!enc || !name || !data_host || !shape || ndim < 1 || ndim > 2) return fail(SQE_ERR_INVALID, "sqe_encoder_load_tensor: bad arguments");
+    CtxGuard g(enc->ctx);
+    hipStream_t st = (hipStream_t)sqe_stream(enc->ctx);
+    const sqe_bert_cfg& c = enc->cfg;
+    const size_t H = c.hidden, I = c.inter;
+    const std::string n(name);
+    size_t count = 1;
+    for (int i = 0; i < ndim; ++i) count *= (size_t)shape[i];
+    auto expect = [&](size_t want) -> int {
+        if (count != want) return fail(SQE_ERR_INVALID, "sqe_encoder_load_tensor: wrong size for " + n);
+        return SQE_OK;
+    };
+    int rc = SQE_OK;
+    if (n == "embeddings.word_embeddings.weight") { SQE_TRY(expect((size_t)c.vocab_size * H)); rc = upload(enc->word, data_host, count, true, 0, count, st); }
+    else if (n == "embeddings.position_embeddings.weight") { SQE_TRY(expect((size_t)c.max_pos * H)); rc = upload(enc->pos, data_host, count, true, 0, count, st); }
+    else if (n == "embeddings.token_type_embeddings.weight") { SQE_TRY(expect((size_t)c.type_vocab * H)); rc = upload(enc->type, data_host, count, true, 0, count, st); }
+    else if (n == "embeddings.LayerNorm.weight") { SQE_TRY(expect(H)); rc = upload(enc->emb_g, data_host, count, false, 0, count, st); }
+    else if (n == "embeddings.LayerNorm.bias") { SQE_TRY(expect(H)); rc = upload(enc->emb_b, data_host, count, false, 0, count, st); }
+    else if (n.rfind("encoder.layer.", 0) == 0) {
+        const size_t dot = n.find('.', 14);
+        if (dot == std::string::npos) return fail(SQE_ERR_INVALID, "unknown tensor " + n);
+        const int l = atoi(n.substr(14, dot - 14).c_str());
+        if (l < 0 || l >= c.layers) return fail(SQE_ERR_INVALID, "layer index out of range in " + n);
+        sqe_layer& L = *enc->layers[l];
+        const std::string s = n.substr(dot + 1);
+        if (s == "attention.self.query.weight") { SQE_TRY(expect(H * H)); rc = upload(L.w_qkv, data_host, count, true, 0, 3 * H * H, st); }
+        else if (s == "attention.self.key.weight") { SQE_TRY(expect(H * H)); rc = upload(L.w_qkv, data_host, count, true, H * H, 3 * H * H, st); }
+        else if (s == "attention.self.value.weight") { SQE_TRY(expect(H * H)); rc = upload(L.w_qkv, data_host, count, true, 2 * H * H, 3 * H * H, st); }
+        else if (s == "attention.self.query.bias") { SQE_TRY(expect(H)); rc = upload(L.b_qkv, data_host, count, false, 0, 3 * H, st); }
+        else if (s == "attention.self.key.bias") { SQE_TRY(expect(H)); rc = upload(L.b_qkv, data_host, count, false, H, 3 * H, st); }
+        else if (s == "attention.self.value.bias") { SQE_TRY(expect(H)); rc = upload(L.b_qkv, data_host, count, false, 2 * H, 3 * H, st); }
+        else if (s == "attention.output.dense.weight") { SQE_TRY(expect(H * H)); rc = upload(L.w_o, data_host, count, true, 0, count, st); }
+        else if (s == "attention.output.dense.bias") { SQE_TRY(expect(H)); rc = upload(L.b_o, data_host, count, false, 0, count, st); }
+        else if (s == "attention.output.LayerNorm.weight") { SQE_TRY(expect(H)); rc = upload(L.ln1_g, data_host, count, false, 0, count, st); }
+        else if (s == "attention.output.LayerNorm.bias") { SQE_TRY(expect(H)); rc = upload(L.ln1_b, data_host, count, false, 0, count, st); }
+        else if (s == "intermediate.dense.weight") { SQE_TRY(expect(I * H)); rc = upload(L.w_1, data_host, count, true, 0, count, st); }
+        else if (s == "intermediate.dense.bias") { SQE_TRY(expect(I)); rc = upload(L.b_1, data_host, count, false, 0, count, st); }
+        else if (s == "output.dense.weight") { SQE_TRY(expect(H * I)); rc = upload(L.w_2, data_host, count, true, 0, count, st); }
+        else if (s == "output.dense.bias") { SQE_TRY(expect(H)); rc = upload(L.b_2, data_host, count, false, 0, count, st); }
+        else if (s == "output.LayerNorm.weight") { SQE_TRY(expect(H)); rc = upload(L.ln2_g, data_host, count, false, 0, count, st); }
+        else if (s == "output.LayerNorm.bias") { SQE_TRY(expect(H)); rc = upload(L.ln2_b, data_host, count, false, 0, count, st); }
+        else return fail(SQE_ERR_INVALID, "unknown tensor " + n);
+    } else {
+        return fail(SQE_ERR_INVALID, "unknown tensor " + n);
+    }
+    if (rc == SQE_OK) { enc->loaded[n] = true; enc->finalized = false; }
+    return rc;
 }
-int sqe_encode_device(sqe_encoder*, const int32_t*, const int32_t*, int, int, float*) {
-    return fail(SQE_ERR_UNSUPPORTED, "encoder: not implemented in this build");
+
+int sqe_encoder_finalize(sqe_encoder* enc) {
+    if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
+    const size_t want = 5 + (size_t)enc->cfg.layers * 16;
+    if (enc->loaded.size() != want)
+        return fail(SQE_ERR_STATE, "sqe_encoder_finalize: " + std::to_string(enc->loaded.size()) + " of " + std::to_string(want) + " tensors loaded");
+    enc->finalized = true;
+    return SQE_OK;
+}
+
+int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev) {
+    if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
+    if (!enc->finalized) return fail(SQE_ERR_STATE, "sqe_encode: encoder weights not finalized");
+    if (B < 0 || S < 1 || S > enc->cfg.max_pos) return fail(SQE_ERR_INVALID, "sqe_encode: need 1 <= S <= max_pos");
+    if (B == 0) return SQE_OK;
+    if (!ids_dev || !lens_dev || !out_dev) return fail(SQE_ERR_INVALID, "sqe_encode: null buffer");
+    CtxGuard g(enc->ctx);
+    hipStream_t st = (hipStream_t)sqe_stream(enc->ctx);
+    const sqe_bert_cfg& c = enc->cfg;
+    const int H = c.hidden, I = c.inter;
+    const int T = B * S;
+    const int t_pad = (T + 255) / 256 * 256;
+    if (t_pad > enc->t_cap) {
+        SQE_TRY(enc->x.alloc((size_t)t_pad * H * 2));
+        SQE_TRY(enc->x1.alloc((size_t)t_pad * H * 2));
+        SQE_TRY(enc->att.alloc((size_t)t_pad * H * 2));
+        SQE_TRY(enc->qkv.alloc((size_t)t_pad * 3 * H * 2));
+        SQE_TRY(enc->hbuf.alloc((size_t)t_pad * I * 2));
+        SQE_TRY(enc->pre.alloc((size_t)t_pad * H * 4));
+        SQE_HIP(hipMemsetAsync(enc->x.p, 0, (size_t)t_pad * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->x1.p, 0, (size_t)t_pad * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->att.p, 0, (size_t)t_pad * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->qkv.p, 0, (size_t)t_pad * 3 * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->hbuf.p, 0, (size_t)t_pad * I * 2, st));
+        enc->t_cap = t_pad;
+    }
+    const int cus = ctx_cu_count(enc->ctx);
+    const int rows4 = (T + 3) / 4;
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows4), dim3(256), 0, st, ids_dev, enc->word.as<bf16_t>(), enc->pos.as<bf16_t>(),
+                       enc->type.as<bf16_t>(), enc->emb_g.as<float>(), enc->emb_b.as<float>(), enc->pre.as<float>(),
+                       enc->x.as<bf16_t>(), T, S, H, c.vocab_size, c.ln_eps);
+    SQE_HIP(hipGetLastError());
+    const int qblocks = (S + 63) / 64;
+    for (int l = 0; l < c.layers; ++l) {
+        sqe_layer& L = *enc->layers[l];
+        GemmArgs a;
+        a.T = T; a.resid = nullptr; a.n_tiles = 0;
+        // E2: QKV projection
+        a.W = L.w_qkv.as<bf16_t>(); a.X = enc->x.as<bf16_t>(); a.bias = L.b_qkv.as<float>(); a.out = enc->qkv.p; a.N = 3 * H; a.K = H;
+        SQE_TRY(launch_gemm<EPI_BIAS>(a, t_pad, cus, st));
+        // E3: attention
+        hipLaunchKernelGGL(attention_kernel, dim3(B * c.heads * qblocks), dim3(256), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
+                           enc->att.as<bf16_t>(), S, H, c.heads);
+        SQE_HIP(hipGetLastError());
+        // E4: output projection + residual, LayerNorm
+        a.W = L.w_o.as<bf16_t>(); a.X = enc->att.as<bf16_t>(); a.bias = L.b_o.as<float>(); a.resid = enc->x.as<bf16_t>();
+        a.out = enc->pre.p; a.N = H; a.K = H;
+        SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st));
+        hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln1_g.as<float>(),
+                           L.ln1_b.as<float>(), enc->x1.as<bf16_t>(), T, H, c.ln_eps);
+        // E5: FFN up + GELU
+        a.W = L.w_1.as<bf16_t>(); a.X = enc->x1.as<bf16_t>(); a.bias = L.b_1.as<float>(); a.resid = nullptr;
+        a.out = enc->hbuf.p; a.N = I; a.K = H;
+        SQE_TRY(launch_gemm<EPI_GELU>(a, t_pad, cus, st));
+        // E6: FFN down + residual, LayerNorm (the last layer's LayerNorm is done by the pooling kernel in fp32)
+        a.W = L.w_2.as<bf16_t>(); a.X = enc->hbuf.as<bf16_t>(); a.bias = L.b_2.as<float>(); a.resid = enc->x1.as<bf16_t>();
+        a.out = enc->pre.p; a.N = H; a.K = I;
+        SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st));
+        if (l + 1 < c.layers) {
+            hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
+                               L.ln2_b.as<float>(), enc->x.as<bf16_t>(), T, H, c.ln_eps);
+        } else {
+            hipLaunchKernelGGL(pool_ln_kernel, dim3((B + 3) / 4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
+                               L.ln2_b.as<float>(), out_dev, B, S, H, c.ln_eps);
+        }
+        SQE_HIP(hipGetLastError());
+    }
+    return SQE_OK;
+}
+
+int sqe_encode(sqe_encoder* enc, const int32_t* ids_host, const int32_t* lens_host, int B, int S, float* out_host) {
+    if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
+    if (B < 0 || S < 1) return fail(SQE_ERR_INVALID, "sqe_encode: bad shape");
+    if (B == 0) return SQE_OK;
+    if (!ids_host || !lens_host || !out_host) return fail(SQE_ERR_INVALID, "sqe_encode: null buffer");
+    CtxGuard g(enc->ctx);
+    hipStream_t st = (hipStream_t)sqe_stream(enc->ctx);
+    SQE_TRY(enc->ids.alloc((size_t)B * S * 4));
+    SQE_TRY(enc->lens.alloc((size_t)B * 4));
+    SQE_TRY(enc->out.alloc((size_t)B * enc->cfg.hidden * 4));
+    SQE_HIP(hipMemcpyAsync(enc->ids.p, ids_host, (size_t)B * S * 4, hipMemcpyHostToDevice, st));
+    SQE_HIP(hipMemcpyAsync(enc->lens.p, lens_host, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    SQE_TRY(sqe_encode_device(enc, enc->ids.as<int32_t>(), enc->lens.as<int32_t>(), B, S, enc->out.as<float>()));
+    SQE_HIP(hipMemcpyAsync(out_host, enc->out.p, (size_t)B * enc->cfg.hidden * 4, hipMemcpyDeviceToHost, st));
+    SQE_HIP(hipStreamSynchronize(st));
+    return SQE_OK;
 }
 
 }  // extern "C"

@@ -50,7 +50,7 @@ struct ScanArgs {
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless
-// the environment sets SQE_SCAN_V0=1 (A/B and fallback).
+// unless the environment sets SQE_SCAN_P8=1 it uses the two-stage form (measured slightly faster).
 int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 
 // ------------------------------------------------------------------ select + rescore (S3+S4)

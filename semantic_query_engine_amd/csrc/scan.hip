@@ -285,7 +285,7 @@ int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream
     if (a.K % SCAN_BK != 0) return fail(SQE_ERR_INVALID, "scan: dim must be a multiple of 64");
     if (plan.kp < 1 || plan.kp > MAX_KP) return fail(SQE_ERR_INVALID, "scan: kp out of range");
     if (plan.bn == 256) {
-        static const bool use_v0 = [] { const char* e = getenv("SQE_SCAN_V0"); return e && e[0] == '1'; }();
+        static const bool use_v0 = [] { const char* e = getenv("SQE_SCAN_P8"); return !(e && e[0] == '1'); }();
         if (!use_v0) return launch_scan_bf16_p8(plan, a, stream);
         return launch_cfg<2, 4, 8, 4>(plan, a, stream);
     }

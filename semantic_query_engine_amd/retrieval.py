@@ -250,3 +250,57 @@ def lfu_cache_get(query_emb: np.ndarray) -> Optional[str]:
 
 def lfu_cache_put(query_emb: np.ndarray, response: str) -> None:
     _cache().put(query_emb, response)
+
+
+# ------------------------------------------------------------------------------ embeddings
+class Embedder:
+    """Tokenizer + encoder pair standing where Ollama stood (main.py:134-145): text -> 1024 floats.
+    No prefix or instruction is added to queries or passages (the reference adds none, main.py:139)."""
+
+    def __init__(self, encoder, tokenizer, max_len: int = 512):
+        self.encoder, self.tokenizer, self.max_len = encoder, tokenizer, max_len
+        self._lock = threading.Lock()
+
+    def embed(self, texts: List[str]) -> np.ndarray:
+        if not texts:
+            return np.zeros((0, self.encoder.cfg["hidden"]), np.float32)
+        ids, lens = self.tokenizer.encode_batch(texts, self.max_len)
+        s = int(min(self.max_len, max(16, (int(lens.max()) + 15) // 16 * 16)))
+        with self._lock:
+            return self.encoder.encode_ids(ids[:, :s], lens)
+
+
+_embedder: Optional[Embedder] = None
+
+
+def configure_embedder(embedder: Embedder) -> None:
+    """Install the process-wide embedder used by the reference-named functions below."""
+    global _embedder
+    _embedder = embedder
+
+
+def _require_embedder() -> Embedder:
+    if _embedder is None:
+        raise RuntimeError("no embedder configured: call configure_embedder(Embedder(encoder, tokenizer))")
+    return _embedder
+
+
+async def ollama_embed_text(text: str, model: str = "mxbai-embed-large:latest") -> List[float]:
+    """main.py:134-145: one text -> its embedding as a list of floats (``model`` kept for call compatibility)."""
+    return _require_embedder().embed([text])[0].tolist()
+
+
+async def embed_texts_in_batches(texts: List[str], batch_size: int = 64) -> np.ndarray:
+    """main.py:148-169: order-preserving embedding of ``texts`` -> float32 [n, 1024]; [] -> np.array([])."""
+    if not texts:
+        return np.array([])
+    emb = _require_embedder()
+    out = [emb.embed(texts[i:i + batch_size]) for i in range(0, len(texts), batch_size)]
+    return np.concatenate(out, axis=0).astype(np.float32)
+
+
+async def embed_query(query: str) -> np.ndarray:
+    """main.py:172-180: one query -> float32 [1, 1024]; blank -> size-0 array."""
+    if not query.strip():
+        return np.array([])
+    return _require_embedder().embed([query]).astype(np.float32)

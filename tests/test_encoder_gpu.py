@@ -1,0 +1,106 @@
+"""Parity of the HIP BERT encoder (through the C ABI) against the fp32 oracle.  GPU only.
+Tolerance: bf16 weights are shared bit-exactly with the oracle (weights rounded to bf16 on both
+sides); activations are bf16 on the GPU, so the bar is cosine >= 0.999 per embedding and
+max-abs error within 3e-2 of the embedding scale (final LayerNorm output, |x| ~ 1)."""
+import asyncio
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bert as OB
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def _encoder(ctx, cfg, w):
+    from semantic_query_engine_amd.encoder import BertEncoder
+    enc = BertEncoder(ctx, vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                      inter=cfg.inter, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab, ln_eps=cfg.ln_eps)
+    enc.load_weights({k: v.numpy() for k, v in w.items()})
+    return enc
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from semantic_query_engine_amd import Context
+    return Context(0)
+
+
+def test_toy_config_matches_oracle_and_golden(ctx, golden_dir):
+    cfg = OB.BertCfg.toy()
+    w = OB.random_weights(cfg, seed=3)
+    g = np.load(os.path.join(golden_dir, "bert_toy.npz"))
+    enc = _encoder(ctx, cfg, w)
+    got = enc.encode_ids(g["ids"], g["lens"])
+    ref = OB.bert_encode(w, cfg, g["ids"], g["lens"])
+    assert np.allclose(ref, g["cls"], atol=1e-5)
+    for i in range(got.shape[0]):
+        assert _cos(got[i], ref[i]) >= 0.999, (i, _cos(got[i], ref[i]))
+    assert np.abs(got - ref).max() < 0.06
+    # padding content is ignored
+    ids2 = g["ids"].copy()
+    ids2[1, 7:] = 0
+    assert np.array_equal(enc.encode_ids(ids2, g["lens"]), got)
+
+
+@pytest.mark.parametrize("b,s", [(1, 16), (3, 64), (2, 130), (5, 48)])
+def test_mid_config_shapes(ctx, b, s):
+    """4 layers, hidden 256, 4 heads: exercises several query blocks, KV blocks and both GEMM tiles."""
+    cfg = OB.BertCfg(vocab_size=1000, hidden=256, layers=4, heads=4, inter=1024, max_pos=256)
+    w = OB.random_weights(cfg, seed=7)
+    rng = np.random.default_rng(b * 100 + s)
+    ids = rng.integers(5, cfg.vocab_size, (b, s))
+    lens = rng.integers(1, s + 1, b)
+    lens[0] = s
+    enc = _encoder(ctx, cfg, w)
+    got = enc.encode_ids(ids, lens)
+    ref = OB.bert_encode(w, cfg, ids, lens)
+    for i in range(b):
+        assert _cos(got[i], ref[i]) >= 0.999, (i, lens[i], _cos(got[i], ref[i]))
+    assert np.abs(got - ref).max() < 0.08
+
+
+def test_bert_large_full_size(ctx):
+    """The real geometry (24 layers, 1024 hidden, 16 heads, 4096 FFN) with seeded random weights."""
+    cfg = OB.BertCfg()
+    w = OB.random_weights(cfg, seed=0)
+    rng = np.random.default_rng(1)
+    ids = rng.integers(1000, cfg.vocab_size, (4, 32))
+    lens = np.array([32, 9, 20, 1])
+    enc = _encoder(ctx, cfg, w)
+    got = enc.encode_ids(ids, lens)
+    ref = OB.bert_encode(w, cfg, ids, lens)
+    cs = [_cos(got[i], ref[i]) for i in range(4)]
+    assert min(cs) >= 0.999, cs
+    assert not np.isnan(got).any()
+
+
+def test_embed_functions_mirror_reference(ctx):
+    from semantic_query_engine_amd import retrieval as RT
+    from semantic_query_engine_amd.tokenizer import WordPieceTokenizer
+    from oracle import wordpiece as WP
+    texts = ["Hypertension affects adults; beta blockers are first line.", "short", "", "A second, longer passage about "
+             "randomised controlled trials and their outcomes in cardiology patients."]
+    vocab = WP.synthetic_vocab(texts, size=600)
+    v = {t: i for i, t in enumerate(vocab)}
+    cfg = OB.BertCfg(vocab_size=len(vocab), hidden=128, layers=2, heads=2, inter=512, max_pos=64)
+    w = OB.random_weights(cfg, seed=5)
+    enc = _encoder(ctx, cfg, w)
+    RT.configure_embedder(RT.Embedder(enc, WordPieceTokenizer(vocab_text="\n".join(vocab) + "\n"), max_len=64))
+    embs = asyncio.run(RT.embed_texts_in_batches(texts, batch_size=3))
+    assert embs.dtype == np.float32 and embs.shape == (4, 128)
+    for i, t in enumerate(texts):
+        ids = WP.encode(t, v, 64)
+        ref = OB.bert_encode(w, cfg, np.array([ids]), np.array([len(ids)]))[0]
+        assert _cos(embs[i], ref) >= 0.999
+    q = asyncio.run(RT.embed_query(texts[0]))
+    assert q.shape == (1, 128) and np.allclose(q[0], embs[0], atol=1e-6)
+    assert asyncio.run(RT.embed_query("   ")).size == 0
+    assert asyncio.run(RT.embed_texts_in_batches([])).size == 0
+    one = asyncio.run(RT.ollama_embed_text(texts[1]))
+    assert isinstance(one, list) and len(one) == 128
