@@ -89,7 +89,10 @@ int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, floa
 
 /* Options: "scan_mode" (SQE_SCAN_*), "rescore_k" (candidates kept by the bf16 scan,
  * 0 = automatic), "nprobe" default for IVF, "id_base" (added to every returned row id:
- * the first global row of this shard in a row-sharded index). */
+ * the first global row of this shard in a row-sharded index), "certify" (default 1: prove
+ * per query that no row outside the re-scored candidates can reach the k-th cosine -- the
+ * bf16 rounding of every vector is bounded -- and re-scan the fp32 master for the queries
+ * where that proof fails; 0 = skip both). */
 int sqe_index_set_option(sqe_index* idx, const char* key, double value);
 
 /* search (main.py:347-373): q is [B, dim] row-major raw query embeddings; each is
@@ -190,6 +193,7 @@ typedef struct sqe_stats_t {
     int64_t scan_rows;     /* rows scanned by the last search */
     int64_t scan_flops;    /* 2 * rows * dim * B of the last search */
     int64_t scan_bytes;    /* algorithmic bytes of the last search */
+    int64_t uncertified;   /* queries of the last search that needed the exact fp32 rescan */
 } sqe_stats_t;
 int sqe_set_profiling(sqe_ctx* ctx, int on);
 int sqe_stats(sqe_ctx* ctx, sqe_stats_t* out);

@@ -114,6 +114,7 @@ struct sqe_ctx {
     std::string name;
     Profiler prof;
     int64_t last_scan_rows = 0, last_scan_flops = 0, last_scan_bytes = 0, search_calls = 0;
+    const int* last_unc_count = nullptr;   // device counter of the last certified search
     DevBuf stage_in;    // generic H2D staging
     DevBuf stage_out;   // generic D2H staging
     DevBuf cache_tmp;   // one-shot cosine scan: matrix + q + sims + best
@@ -139,6 +140,11 @@ struct sqe_index {
     DevBuf cand_cnt;               // [n_chunks, b_pad] int
     DevBuf gmax;                   // [b_pad, ngroups, 64] u32 chunk maxima (global bound table)
     DevBuf dbg;                    // 8 x u64 debug counters (SQE_DBG bit 32)
+    DevBuf resid_max;              // u32 float bits: max over rows of || x_hat - bf16(x_hat) ||
+    DevBuf q_resid;                // [B] the same per query
+    DevBuf unc;                    // int count | int list[B] | float thr[B]  (queue of uncertified queries)
+    DevBuf fb_keys, fb_cnt;        // exact-rescan collection buffers
+    int certify = 1;               // run the exactness certificate + fp32 rescan fallback
 };
 
 struct sqe_cache {
@@ -306,7 +312,8 @@ void sqe_index_destroy(sqe_index* idx) {
         (void)hipStreamSynchronize(idx->ctx->stream);
         if (idx->master) (void)hipFree(idx->master);
         if (idx->scan) (void)hipFree(idx->scan);
-        idx->qn.release(); idx->qb.release(); idx->cand.release(); idx->cand_cnt.release(); idx->gmax.release();
+        idx->qn.release(); idx->qb.release(); idx->cand.release(); idx->cand_cnt.release(); idx->gmax.release(); idx->dbg.release(); idx->resid_max.release(); idx->q_resid.release(); idx->unc.release();
+        idx->fb_keys.release(); idx->fb_cnt.release();
     }
     delete idx;
 }
@@ -325,10 +332,15 @@ int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n) {
     if (n == 0) return SQE_OK;
     if (idx->n + n > 0xFFFFFFF0LL) return fail(SQE_ERR_INVALID, "sqe_index_add: more than 2^32 rows per shard");
     SQE_TRY(index_grow(idx, idx->n + n));
+    if (!idx->resid_max.p) {
+        SQE_TRY(idx->resid_max.ensure(16));
+        SQE_HIP(hipMemsetAsync(idx->resid_max.p, 0, 16, idx->ctx->stream));
+    }
     {
         StageTimer t(idx->ctx->prof, idx->ctx->stream, ST_ADD);
         SQE_TRY(launch_normalize_rows(x_dev, n, idx->dim, idx->master + (size_t)idx->n * idx->dim,
-                                      idx->scan + (size_t)idx->n * (idx->pitch / 2), idx->pitch / 2, idx->ctx->stream));
+                                      idx->scan + (size_t)idx->n * (idx->pitch / 2), idx->pitch / 2, nullptr,
+                                      idx->resid_max.as<uint32_t>(), idx->ctx->stream));
     }
     idx->n += n;
     return SQE_OK;
@@ -366,7 +378,7 @@ int sqe_index_update(sqe_index* idx, const int64_t* rows_host, const float* x_ho
     SQE_HIP(hipMemcpyAsync(c->stage_in.p, x_host, xb, hipMemcpyHostToDevice, c->stream));
     SQE_HIP(hipMemcpyAsync((char*)c->stage_in.p + xb, rows_host, rb, hipMemcpyHostToDevice, c->stream));
     SQE_TRY(launch_normalize_rows_scatter(c->stage_in.as<float>(), (const int64_t*)((char*)c->stage_in.p + xb), n,
-                                          idx->dim, idx->master, idx->scan, idx->pitch / 2, c->stream));
+                                          idx->dim, idx->master, idx->scan, idx->pitch / 2, idx->resid_max.as<uint32_t>(), c->stream));
     SQE_HIP(hipStreamSynchronize(c->stream));
     return SQE_OK;
 }
@@ -404,6 +416,8 @@ int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
         idx->rescore_k = (int)value;
     } else if (k == "nprobe") {
         idx->nprobe = (int)value;
+    } else if (k == "certify") {
+        idx->certify = value != 0.0;
     } else if (k == "id_base") {
         if (value < 0) return fail(SQE_ERR_INVALID, "id_base must be >= 0");
         idx->id_base = (int64_t)value;
@@ -432,11 +446,23 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     SQE_TRY(idx->cand_cnt.ensure((size_t)plan.n_chunks * plan.b_pad * 4));
     const size_t gmax_bytes = (size_t)plan.b_pad * plan.ngroups * GMAX_COLS * 4;
     SQE_TRY(idx->gmax.ensure(gmax_bytes));
+    const bool certify = idx->certify && idx->n > 0;
+    SQE_TRY(idx->q_resid.ensure((size_t)B * 4));
+    if (certify) {
+        SQE_TRY(idx->unc.ensure(16 + (size_t)B * 8));
+        SQE_TRY(idx->fb_keys.ensure((size_t)B * EXACT_CAP * 8));
+        SQE_TRY(idx->fb_cnt.ensure((size_t)B * 4));
+    }
     {
         StageTimer t(c->prof, c->stream, ST_PREP);
         if (plan.b_pad > B)
             SQE_HIP(hipMemsetAsync(idx->qb.as<char>() + (size_t)B * idx->pitch, 0, (size_t)(plan.b_pad - B) * idx->pitch, c->stream));
-        SQE_TRY(launch_normalize_rows(q_dev, B, K, idx->qn.as<float>(), idx->qb.as<bf16_t>(), idx->pitch / 2, c->stream));
+        SQE_TRY(launch_normalize_rows(q_dev, B, K, idx->qn.as<float>(), idx->qb.as<bf16_t>(), idx->pitch / 2,
+                                      idx->q_resid.as<float>(), nullptr, c->stream));
+        if (certify) {
+            SQE_HIP(hipMemsetAsync(idx->unc.p, 0, 16, c->stream));
+            SQE_HIP(hipMemsetAsync(idx->fb_cnt.p, 0, (size_t)B * 4, c->stream));
+        }
         SQE_HIP(hipMemsetAsync(idx->gmax.p, 0, gmax_bytes, c->stream));
     }
     if (idx->n > 0) {
@@ -465,7 +491,22 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         s.n_chunks = plan.n_chunks; s.b_pad = plan.b_pad; s.kp = kp;
         s.master = idx->master; s.qn = idx->qn.as<float>(); s.K = K; s.B = B; s.k = k;
         s.cos_out = cos_out_dev; s.id_out = id_out_dev; s.id_base = idx->id_base;
+        int* unc_count = certify ? idx->unc.as<int>() : nullptr;
+        int* unc_list = certify ? idx->unc.as<int>() + 4 : nullptr;
+        float* unc_thr = certify ? reinterpret_cast<float*>(idx->unc.as<int>() + 4 + B) : nullptr;
+        s.q_resid = certify ? idx->q_resid.as<float>() : nullptr;
+        s.db_resid_max = certify ? idx->resid_max.as<uint32_t>() : nullptr;
+        s.unc_count = unc_count; s.unc_list = unc_list; s.unc_thr = unc_thr;
         SQE_TRY(launch_select_rescore(s, c->stream));
+        if (certify) {
+            ExactArgs e;
+            e.master = idx->master; e.qn = idx->qn.as<float>(); e.n_rows = idx->n; e.K = K; e.B = B; e.k = k;
+            e.unc_count = unc_count; e.unc_list = unc_list; e.unc_thr = unc_thr;
+            e.keys = idx->fb_keys.as<uint64_t>(); e.key_cnt = idx->fb_cnt.as<int>();
+            e.cos_out = cos_out_dev; e.id_out = id_out_dev; e.id_base = idx->id_base;
+            SQE_TRY(launch_exact_rescan(e, c->cu_count, c->stream));
+            c->last_unc_count = unc_count;
+        }
     }
     if (idx->dbg.p) {
         unsigned long long h[8];
@@ -649,6 +690,10 @@ int sqe_stats(sqe_ctx* ctx, sqe_stats_t* out) {
     out->scan_rows = ctx->last_scan_rows;
     out->scan_flops = ctx->last_scan_flops;
     out->scan_bytes = ctx->last_scan_bytes;
+    if (ctx->last_unc_count) {
+        int v = 0;
+        if (hipMemcpy(&v, ctx->last_unc_count, 4, hipMemcpyDeviceToHost) == hipSuccess) out->uncertified = v;
+    }
     return SQE_OK;
 }
 

@@ -10,11 +10,14 @@ namespace sqe {
 // bf16 copy (the scanned copy).  Either output may be null.  dim % 4 == 0.
 // `bf16_pitch` = elements between consecutive bf16 output rows (>= dim; the scanned copy pads
 // its rows so that consecutive rows do not map to the same memory channel).
+// `resid_rows` (per row) / `resid_max` (atomic max, float bits) receive || x_hat - bf16(x_hat) ||_2;
+// either may be null.
 int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
-                          int bf16_pitch, hipStream_t stream);
+                          int bf16_pitch, float* resid_rows, uint32_t* resid_max, hipStream_t stream);
 // Same, rows scattered to out row ids `rows[i]` (sqe_index_update).
 int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
-                                  float* out_f32, bf16_t* out_bf16, int bf16_pitch, hipStream_t stream);
+                                  float* out_f32, bf16_t* out_bf16, int bf16_pitch, uint32_t* resid_max,
+                                  hipStream_t stream);
 
 // ------------------------------------------------------------------ flat scan (S2)
 constexpr int SCAN_BM = 256;        // DB rows per tile
@@ -64,8 +67,33 @@ struct SelectArgs {
     float* cos_out;        // [B, k]
     int64_t* id_out;       // [B, k]
     int64_t id_base;       // added to local row ids
+    // exactness certificate (all null = off): a query whose k-th re-scored cosine does not beat the
+    // best score any unseen row could have is queued for the exact fp32 rescan (exact.hip)
+    const float* q_resid;          // [B]  || q_hat - bf16(q_hat) ||
+    const uint32_t* db_resid_max;  // max over rows of || x_hat - bf16(x_hat) || (float bits)
+    int* unc_count;                // number of queued queries
+    int* unc_list;                 // [B] queued query ids
+    float* unc_thr;                // [B] (indexed by queue position) lower bound of the k-th best true cosine
 };
 int launch_select_rescore(const SelectArgs& args, hipStream_t stream);
+
+// ------------------------------------------------------------------ exact fp32 rescan (fallback)
+constexpr int EXACT_CAP = 4096;    // keys collected per queued query
+struct ExactArgs {
+    const float* master;   // [n_rows, K]
+    const float* qn;       // [B, K] normalised queries
+    int64_t n_rows;
+    int K, B, k;
+    const int* unc_count;
+    const int* unc_list;
+    const float* unc_thr;
+    uint64_t* keys;        // [B, EXACT_CAP]
+    int* key_cnt;          // [B], zeroed before the launch
+    float* cos_out;
+    int64_t* id_out;
+    int64_t id_base;
+};
+int launch_exact_rescan(const ExactArgs& args, int cu_count, hipStream_t stream);
 
 // merge of [P,B,k] partial results (multi-GPU all-gather output)
 int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,

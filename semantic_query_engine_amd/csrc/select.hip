@@ -23,6 +23,11 @@ struct SelectKernelArgs {
     float* cos_out;
     int64_t* id_out;
     int64_t id_base;
+    const float* q_resid;
+    const uint32_t* db_resid_max;
+    int* unc_count;
+    int* unc_list;
+    float* unc_thr;
 };
 
 // MSB-first byte-wise radix select of the `kth` largest key among the valid candidates of
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
     __shared__ int scratch[4];
     __shared__ uint32_t sel_row[MAX_KP];
     __shared__ float sel_score[MAX_KP];
+    __shared__ float kth_score;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
     }
     __syncthreads();
     const int m = min(scratch[2], p.kp);
+    if (tid == 0) kth_score = -INFINITY;
 
     // fp32 re-score: one wave per candidate, float4 per lane per step
     const float4* qv = reinterpret_cast<const float4*>(p.qn + (size_t)q * p.K);
@@ -125,10 +132,29 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
             cos_out[rank] = si;
             id_out[rank] = (int64_t)ri + p.id_base;
         }
+        if (rank == p.k - 1) kth_score = si;
     }
     for (int i = m + tid; i < p.k; i += SEL_THREADS) {
         cos_out[i] = -INFINITY;
         id_out[i] = -1;
+    }
+    // ---- exactness certificate.  Rows that are not candidates have a scan key below T, i.e. a bf16
+    // scan score <= score(T); a scan score differs from the true fp32 cosine by at most
+    //   |<q_b, x_b> - <q, x>| <= ||q_b|| * ||x - x_b|| + ||q - q_b|| * ||x||  (+ fp32 accumulation),
+    // so no unseen row can reach score(T) + eps.  T == 0: every row of the index is a candidate.
+    if (p.unc_count) {
+        __syncthreads();
+        if (tid == 0 && T != 0ull) {
+            const float dq = p.q_resid[q];
+            const float dx = __uint_as_float(*p.db_resid_max);
+            const float eps = (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + 2.0e-4f;
+            const bool certified = m >= p.k && kth_score > key_score(T) + eps;
+            if (!certified) {
+                const int slot = atomicAdd(p.unc_count, 1);
+                p.unc_list[slot] = q;
+                p.unc_thr[slot] = m >= p.k ? kth_score : -INFINITY;
+            }
+        }
     }
 }
 
@@ -187,6 +213,8 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.n_chunks = a.n_chunks; k.b_pad = a.b_pad; k.kp = a.kp;
     k.master = a.master; k.qn = a.qn; k.K = a.K; k.B = a.B; k.k = a.k;
     k.cos_out = a.cos_out; k.id_out = a.id_out; k.id_base = a.id_base;
+    k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max; k.unc_count = a.unc_count; k.unc_list = a.unc_list;
+    k.unc_thr = a.unc_thr;
     hipLaunchKernelGGL(select_rescore_kernel, dim3(a.B), dim3(SEL_THREADS), 0, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;

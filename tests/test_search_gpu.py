@@ -109,6 +109,13 @@ def test_adversarial_orderings(ctx):
     cos, ids = idx.search(q, 10)
     ref_cos, ref_ids = R.knn_search(x, q, 10)
     assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q), tol=1e-7)
+    # ~1200 rows sit within bf16 resolution of the best score: the certificate must have failed and
+    # the exact fp32 rescan produced the answer
+    assert ctx.stats()["uncertified"] >= 1
+    idx.set_option("certify", 0)
+    cos_nc, ids_nc = idx.search(q, 10)
+    assert not np.array_equal(ids_nc[0], ref_ids[0])          # what the bf16 scan alone would return
+    idx.set_option("certify", 1)
     same = np.tile(np.linspace(-1, 1, d, dtype=np.float32), (7000, 1))
     idx2 = _index(ctx, same)
     cos, ids = idx2.search(same[:3] * 5.0, 10)
@@ -131,6 +138,7 @@ def test_config2_shape_recall(ctx):
     assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
     assert np.array_equal(ids[: b // 2, 0], plant)
     assert np.abs(cos - ref_cos).max() < 1e-5
+    assert ctx.stats()["uncertified"] <= b // 50              # the certificate holds for almost every query
 
 
 def test_profiling_stats(ctx):
