@@ -248,6 +248,7 @@ def main():
                                    f"batch={b} queries/step, index row-sharded over {world} GPU(s)",
                        "rows": n_total, "dim": D, "batch": b, "k": k, "parallelism": f"shard{world}"},
             "recall_at_10": round(recall, 4), "max_abs_dcos": max_dcos, "planted_top1_ok": planted_ok,
+            "uncertified_queries_last_step": int(st.get("uncertified", 0)),
             "stage_ms": {"prep": round(st["prep_ms"] / args.steps, 4), "scan": round(scan_ms, 4),
                          "select_rescore": round(st["select_ms"] / args.steps, 4)},
             "roofline": roof,

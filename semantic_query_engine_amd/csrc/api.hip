@@ -196,8 +196,10 @@ int index_grow(sqe_index* idx, int64_t need_rows) {
 
 int auto_kp(const sqe_index* idx, int k) {
     if (idx->rescore_k > 0) return std::min(MAX_KP, std::max(idx->rescore_k, k));
-    // bf16 scores of unit vectors carry ~1e-4 absolute error: keep a 3x margin, at least 32
-    return std::min(MAX_KP, std::max(32, 3 * k));
+    // The certificate needs the kp-th scan score to sit more than eps (~2.5e-3 at dim 1024) below the
+    // k-th true cosine.  On 10M random rows the 10th -> 32nd gap is only ~3 sigma above eps (a few
+    // queries per 1024 would need the fp32 rescan); 10th -> 64th makes that a 1e-5 event.
+    return std::min(MAX_KP, std::max(idx->certify ? 64 : 32, 4 * k));
 }
 
 }  // namespace
