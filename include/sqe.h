@@ -109,6 +109,9 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
 /* IVF only: k-means (spherical, Lloyd) on a sample, then (re)assignment of stored rows. */
 int sqe_index_train(sqe_index* idx, const float* x_host, int64_t n, int iters, uint64_t seed);
 int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int iters, uint64_t seed);
+/* IVF introspection: normalised centroids [nlist, dim] and the list of every stored row [count]
+ * (either pointer may be NULL). */
+int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host);
 
 /* Merge of per-shard results after the all-gather of a row-sharded index: part p holds
  * cos [B,k] fp32 at cos_parts_dev + p * part_stride_bytes and global ids [B,k] int64

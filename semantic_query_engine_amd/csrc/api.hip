@@ -104,6 +104,8 @@ struct StageTimer {
 using namespace sqe;
 
 // ================================================================ objects
+namespace sqe { struct IvfState; }
+
 struct sqe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream in use
@@ -145,6 +147,7 @@ struct sqe_index {
     DevBuf unc;                    // int count | int list[B] | float thr[B]  (queue of uncertified queries)
     DevBuf fb_keys, fb_cnt;        // exact-rescan collection buffers
     int certify = 1;               // run the exactness certificate + fp32 rescan fallback
+    sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
 };
 
 struct sqe_cache {
@@ -204,8 +207,29 @@ int auto_kp(const sqe_index* idx, int k) {
 
 }  // namespace
 
-// accessors used by encoder.hip (sqe_ctx is defined in this file only)
+// IVF layer (ivf.hip)
 namespace sqe {
+struct IvfState;
+int ivf_create(sqe_index* base, IvfState** out);
+void ivf_destroy(IvfState* st);
+int ivf_rows_added(sqe_index* base, IvfState* st);
+int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int iters, uint64_t seed);
+int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, int nprobe, float* cos_out, int64_t* id_out);
+int ivf_export(sqe_index* base, IvfState* st, float* centroids_host, int32_t* assign_host);
+void ivf_invalidate(IvfState* st);
+sqe_index* ivf_coarse(IvfState* st);
+}  // namespace sqe
+
+// accessors used by encoder.hip / ivf.hip (sqe_ctx and sqe_index are defined in this file only)
+namespace sqe {
+float* index_master(sqe_index* idx) { return idx->master; }
+int64_t index_rows(sqe_index* idx) { return idx->n; }
+int index_dim(sqe_index* idx) { return idx->dim; }
+int index_nlist(sqe_index* idx) { return idx->nlist; }
+int64_t index_id_base(sqe_index* idx) { return idx->id_base; }
+sqe_ctx* index_ctx(sqe_index* idx) { return idx->ctx; }
+void index_clear(sqe_index* idx) { idx->n = 0; }
+hipStream_t ctx_stream(sqe_ctx* ctx) { return ctx->stream; }
 int ctx_cu_count(sqe_ctx* ctx) { return ctx->cu_count; }
 int ctx_device(sqe_ctx* ctx) { return ctx->device; }
 void ctx_lock(sqe_ctx* ctx) { ctx->mu.lock(); }
@@ -287,8 +311,9 @@ int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out
     *out = nullptr;
     if (dim <= 0 || dim % SCAN_BK != 0 || dim > 8192)
         return fail(SQE_ERR_INVALID, "sqe_index_create: dim must be a positive multiple of 64 (<= 8192)");
-    if (kind != SQE_INDEX_FLAT)
-        return fail(SQE_ERR_UNSUPPORTED, "sqe_index_create: only SQE_INDEX_FLAT is implemented in this build");
+    if (kind != SQE_INDEX_FLAT && kind != SQE_INDEX_IVF_FLAT) return fail(SQE_ERR_INVALID, "sqe_index_create: unknown index kind");
+    if (kind == SQE_INDEX_IVF_FLAT && (nlist < 1 || nlist > (1 << 20)))
+        return fail(SQE_ERR_INVALID, "sqe_index_create: IVF needs 1 <= nlist <= 2^20");
     sqe_index* idx = new (std::nothrow) sqe_index;
     if (!idx) return fail(SQE_ERR_OOM, "sqe_index_create: host allocation failed");
     idx->ctx = ctx;
@@ -302,12 +327,18 @@ int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out
         const int pad = e ? atoi(e) : 128;
         idx->pitch = dim * 2 + (pad >= 0 && pad % 8 == 0 ? pad : 128);
     }
+    if (kind == SQE_INDEX_IVF_FLAT) {
+        int rc = ivf_create(idx, &idx->ivf);
+        if (rc == SQE_OK) rc = sqe_index_set_option(ivf_coarse(idx->ivf), "certify", 0.0);   // probes are approximate by nature
+        if (rc != SQE_OK) { ivf_destroy(idx->ivf); delete idx; return rc; }
+    }
     *out = idx;
     return SQE_OK;
 }
 
 void sqe_index_destroy(sqe_index* idx) {
     if (!idx) return;
+    if (idx->ivf) { ivf_destroy(idx->ivf); idx->ivf = nullptr; }
     {
         std::lock_guard<std::recursive_mutex> lk(idx->ctx->mu);
         (void)hipSetDevice(idx->ctx->device);
@@ -345,6 +376,7 @@ int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n) {
                                       idx->resid_max.as<uint32_t>(), idx->ctx->stream));
     }
     idx->n += n;
+    if (idx->ivf) SQE_TRY(ivf_rows_added(idx, idx->ivf));
     return SQE_OK;
 }
 
@@ -382,6 +414,7 @@ int sqe_index_update(sqe_index* idx, const int64_t* rows_host, const float* x_ho
     SQE_TRY(launch_normalize_rows_scatter(c->stage_in.as<float>(), (const int64_t*)((char*)c->stage_in.p + xb), n,
                                           idx->dim, idx->master, idx->scan, idx->pitch / 2, idx->resid_max.as<uint32_t>(), c->stream));
     SQE_HIP(hipStreamSynchronize(c->stream));
+    if (idx->ivf) ivf_invalidate(idx->ivf);       // overwritten rows are re-assigned at the next search
     return SQE_OK;
 }
 
@@ -437,6 +470,12 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     if (B < 0 || k < 1 || k > MAX_KP) return fail(SQE_ERR_INVALID, "sqe_index_search: need B >= 0 and 1 <= k <= 256");
     if (B == 0) return SQE_OK;
     if (!q_dev || !cos_out_dev || !id_out_dev) return fail(SQE_ERR_INVALID, "sqe_index_search: null buffer");
+    if (idx->ivf) {
+        StageTimer t(idx->ctx->prof, idx->ctx->stream, ST_SCAN);
+        SQE_TRY(ivf_search(idx, idx->ivf, q_dev, B, k, nprobe > 0 ? nprobe : idx->nprobe, cos_out_dev, id_out_dev));
+        idx->ctx->search_calls++;
+        return SQE_OK;
+    }
     sqe_ctx* c = idx->ctx;
     const int K = idx->dim;
     const int kp = auto_kp(idx, k);
@@ -544,13 +583,32 @@ int sqe_index_search(sqe_index* idx, const float* q_host, int B, int k, int npro
     return SQE_OK;
 }
 
-int sqe_index_train(sqe_index* idx, const float*, int64_t, int, uint64_t) {
+int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int iters, uint64_t seed) {
     if (!idx) return fail(SQE_ERR_INVALID, "null index");
-    return fail(SQE_ERR_UNSUPPORTED, "sqe_index_train: IVF is not implemented in this build");
+    SQE_ENTER(idx->ctx);
+    if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_train: not an IVF index");
+    if (!x_dev || n <= 0) return fail(SQE_ERR_INVALID, "sqe_index_train: empty training set");
+    return ivf_train(idx, idx->ivf, x_dev, n, iters, seed);
 }
-int sqe_index_train_device(sqe_index* idx, const float*, int64_t, int, uint64_t) {
+
+int sqe_index_train(sqe_index* idx, const float* x_host, int64_t n, int iters, uint64_t seed) {
     if (!idx) return fail(SQE_ERR_INVALID, "null index");
-    return fail(SQE_ERR_UNSUPPORTED, "sqe_index_train: IVF is not implemented in this build");
+    SQE_ENTER(idx->ctx);
+    if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_train: not an IVF index");
+    if (!x_host || n <= 0) return fail(SQE_ERR_INVALID, "sqe_index_train: empty training set");
+    DevBuf tmp;
+    SQE_TRY(tmp.ensure((size_t)n * idx->dim * 4));
+    SQE_HIP(hipMemcpyAsync(tmp.p, x_host, (size_t)n * idx->dim * 4, hipMemcpyHostToDevice, idx->ctx->stream));
+    SQE_TRY(ivf_train(idx, idx->ivf, tmp.as<float>(), n, iters, seed));
+    SQE_HIP(hipStreamSynchronize(idx->ctx->stream));
+    return SQE_OK;
+}
+
+int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host) {
+    if (!idx) return fail(SQE_ERR_INVALID, "null index");
+    SQE_ENTER(idx->ctx);
+    if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_ivf_export: not an IVF index");
+    return ivf_export(idx, idx->ivf, centroids_host, assign_host);
 }
 
 int sqe_merge_topk_device(sqe_ctx* ctx, const float* cos_parts_dev, const int64_t* id_parts_dev,

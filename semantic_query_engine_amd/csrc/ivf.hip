@@ -1,0 +1,483 @@
+// ivf.hip -- IVF-flat on top of the flat index (BASELINE config 5: nlist = 4096, nprobe = 32).
+//
+//   train   spherical k-means (Lloyd): assignment = flat cosine top-1 of the sample against the
+//           current centroids (the bf16 MFMA scan + fp32 rescore of the flat path, S7 "assign"),
+//           update = segmented sum by fp32 atomics + renormalise (S7 "update")
+//   add     rows are stored by the base flat index (fp32 master + bf16 copy); each row is assigned
+//           to its best centroid; the inverted lists (row ids grouped by list) are rebuilt lazily
+//   search  S5 coarse quantise = flat top-nprobe over the centroids; S6 list scan = for every list
+//           the queries probing it x the list's rows, exact fp32 cosines from the master (rows are
+//           gathered by id, 4 KiB each), written to a per-(query, probe) score strip; a per-query
+//           radix select over its nprobe strips gives the exact top-k of the probed rows.
+//
+// The list scan is HBM-bound: with B = 1024 and nprobe = 32 nearly every list is probed, so one
+// batch reads the fp32 master about once (41 GB at N = 10M).  Scores are exact fp32, so no rescore.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "kernels.h"
+
+struct sqe_index;
+struct sqe_ctx;
+
+// internal hooks implemented in api.hip
+namespace sqe {
+float* index_master(sqe_index* idx);
+int64_t index_rows(sqe_index* idx);
+int index_dim(sqe_index* idx);
+int index_nlist(sqe_index* idx);
+int64_t index_id_base(sqe_index* idx);
+sqe_ctx* index_ctx(sqe_index* idx);
+void index_clear(sqe_index* idx);
+hipStream_t ctx_stream(sqe_ctx* ctx);
+int ctx_cu_count(sqe_ctx* ctx);
+}  // namespace sqe
+
+extern "C" {
+int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out);
+void sqe_index_destroy(sqe_index* idx);
+int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n);
+int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, int nprobe, float* cos_out_dev,
+                            int64_t* id_out_dev);
+}
+
+namespace sqe {
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int ensure(size_t need) {
+        if (need <= bytes) return SQE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return fail(SQE_ERR_OOM, std::string("ivf hipMalloc: ") + hipGetErrorString(e));
+        bytes = need;
+        return SQE_OK;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+constexpr int IVF_QG = 8;               // queries per pass of the list scan
+constexpr int IVF_QLDS = 8192;          // floats of LDS for the query group
+
+// ---------------------------------------------------------------- small kernels
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          int n, int dim, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float4* s = reinterpret_cast<const float4*>(x + (size_t)idx[r] * dim);
+    float4* d = reinterpret_cast<float4*>(out + (size_t)r * dim);
+    for (int v = lane; v < (dim >> 2); v += 64) d[v] = s[v];
+}
+
+// sums[assign[r]] += x[r] (fp32 atomics, 256 contiguous bytes per wave-instruction); counts[assign[r]]++
+__global__ __launch_bounds__(256) void kmeans_accum_kernel(const float* __restrict__ x, const int64_t* __restrict__ assign,
+                                                           int64_t n, int dim, float* __restrict__ sums,
+                                                           int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t a = assign[r];
+    if (a < 0) return;
+    const float* s = x + (size_t)r * dim;
+    float* d = sums + (size_t)a * dim;
+    for (int i = lane; i < dim; i += 64) atomicAdd(d + i, s[i]);
+    if (lane == 0) atomicAdd(counts + a, 1);
+}
+
+// centroid = sums / ||sums|| where the list is non-empty; empty lists keep their old centroid
+__global__ __launch_bounds__(256) void kmeans_finish_kernel(float* __restrict__ centroids, const float* __restrict__ sums,
+                                                            const int* __restrict__ counts, int nlist, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nlist || counts[c] == 0) return;
+    const float* s = sums + (size_t)c * dim;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) ss += s[i] * s[i];
+    const float den = sqrtf(wave_sum(ss)) + 1e-9f;
+    for (int i = lane; i < dim; i += 64) centroids[(size_t)c * dim + i] = s[i] / den;
+}
+
+__global__ void ivf_store_assign_kernel(const int64_t* __restrict__ ids, int64_t n, int* __restrict__ assign,
+                                        int* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = (int)ids[i];
+    assign[i] = a;
+    if (counts && a >= 0) atomicAdd(counts + a, 1);
+}
+
+__global__ void ivf_count_kernel(const int* __restrict__ assign, int64_t n, int* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && assign[i] >= 0) atomicAdd(counts + assign[i], 1);
+}
+
+__global__ void ivf_scatter_kernel(const int* __restrict__ assign, int64_t n, const int64_t* __restrict__ offsets,
+                                   int* __restrict__ cursor, int* __restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = assign[i];
+    if (a < 0) return;
+    order[offsets[a] + atomicAdd(cursor + a, 1)] = (int)i;
+}
+
+// (query, probe) pairs bucketed by list
+__global__ void ivf_bucket_kernel(const int64_t* __restrict__ probes, int B, int nprobe, int* __restrict__ lcount,
+                                  int* __restrict__ lq, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nprobe) return;
+    const int64_t L = probes[i];
+    if (L < 0) return;
+    const int slot = atomicAdd(lcount + L, 1);
+    if (slot < cap) lq[(size_t)L * cap + slot] = i;
+}
+
+// S6: one workgroup per list; exact fp32 cosines of the list's rows against the queries probing it
+__global__ __launch_bounds__(256) void ivf_list_scan_kernel(const float* __restrict__ master, const float* __restrict__ qn,
+                                                            const int* __restrict__ order,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const int* __restrict__ lcount, const int* __restrict__ lq,
+                                                            int cap, int nprobe, int K, int max_len,
+                                                            float* __restrict__ pair_scores) {
+    __shared__ __attribute__((aligned(16))) float sq[IVF_QLDS];
+    __shared__ int spair[IVF_QG];
+    const int L = blockIdx.x;
+    const int m = min(lcount[L], cap);
+    const int64_t off = offsets[L];
+    const int len = (int)(offsets[L + 1] - off);
+    if (m == 0 || len == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qg = min(IVF_QG, IVF_QLDS / K);
+    const int nvec = K >> 2;
+    for (int g0 = 0; g0 < m; g0 += qg) {
+        const int gq = min(qg, m - g0);
+        __syncthreads();
+        if (tid < gq) spair[tid] = lq[(size_t)L * cap + g0 + tid];
+        __syncthreads();
+        for (int i = tid; i < gq * K; i += 256) {
+            const int j = i / K, d = i - j * K;
+            sq[i] = qn[(size_t)(spair[j] / nprobe) * K + d];
+        }
+        __syncthreads();
+        for (int i = wave; i < len; i += 4) {
+            const float4* rv = reinterpret_cast<const float4*>(master + (size_t)order[off + i] * K);
+            float acc[IVF_QG];
+#pragma unroll
+            for (int j = 0; j < IVF_QG; ++j) acc[j] = 0.f;
+            for (int v = lane; v < nvec; v += 64) {
+                const float4 a = rv[v];
+#pragma unroll
+                for (int j = 0; j < IVF_QG; ++j) {
+                    if (j < gq) {
+                        const float4 b = *reinterpret_cast<const float4*>(&sq[j * K + v * 4]);
+                        acc[j] = fmaf(a.x, b.x, acc[j]); acc[j] = fmaf(a.y, b.y, acc[j]);
+                        acc[j] = fmaf(a.z, b.z, acc[j]); acc[j] = fmaf(a.w, b.w, acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < IVF_QG; ++j) {
+                if (j < gq) {
+                    const float s = wave_sum(acc[j]) + 0.0f;
+                    if (lane == 0) pair_scores[(size_t)spair[j] * max_len + i] = s;
+                }
+            }
+        }
+    }
+}
+
+// per query: exact top-k over the score strips of its probed lists (key = score desc, row id asc)
+__global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
+                                                         const int* __restrict__ order, const float* __restrict__ pair_scores,
+                                                         int nprobe, int max_len, int k, int64_t id_base,
+                                                         float* __restrict__ cos_out, int64_t* __restrict__ id_out) {
+    __shared__ int hist[256];
+    __shared__ int scratch[4];
+    __shared__ uint64_t top[MAX_KP];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    auto key_at = [&](int p, int i, int64_t off) {
+        return make_key(pair_scores[((size_t)q * nprobe + p) * max_len + i], (uint32_t)order[off + i]);
+    };
+    // total number of probed rows
+    int total = 0;
+    for (int p = 0; p < nprobe; ++p) {
+        const int64_t L = probes[(size_t)q * nprobe + p];
+        if (L >= 0) total += (int)(offsets[L + 1] - offsets[L]);
+    }
+    uint64_t prefix = 0;
+    int remaining = k;
+    const bool all = total <= k;
+    for (int byte = 7; byte >= 0 && !all; --byte) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int shift = byte * 8;
+        for (int p = 0; p < nprobe; ++p) {
+            const int64_t L = probes[(size_t)q * nprobe + p];
+            if (L < 0) continue;
+            const int64_t off = offsets[L];
+            const int len = (int)(offsets[L + 1] - off);
+            for (int i = tid; i < len; i += 256) {
+                const uint64_t key = key_at(p, i, off);
+                const float sc = key_score(key);
+                if (sc != sc) continue;                                   // NaN rows never rank
+                if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+                    atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, bin = 255;
+            for (; bin >= 0; --bin) {
+                if (cum + hist[bin] >= remaining) break;
+                cum += hist[bin];
+            }
+            scratch[0] = bin < 0 ? 0 : bin;
+            scratch[1] = bin < 0 ? remaining : remaining - cum;
+        }
+        __syncthreads();
+        prefix |= ((uint64_t)scratch[0] << shift);
+        remaining = scratch[1];
+        __syncthreads();
+    }
+    const uint64_t T = all ? 0ull : prefix;
+    if (tid == 0) scratch[2] = 0;
+    __syncthreads();
+    for (int p = 0; p < nprobe; ++p) {
+        const int64_t L = probes[(size_t)q * nprobe + p];
+        if (L < 0) continue;
+        const int64_t off = offsets[L];
+        const int len = (int)(offsets[L + 1] - off);
+        for (int i = tid; i < len; i += 256) {
+            const uint64_t key = key_at(p, i, off);
+            const float sc = key_score(key);
+            if (sc == sc && key >= T) {
+                const int slot = atomicAdd(&scratch[2], 1);
+                if (slot < MAX_KP) top[slot] = key;
+            }
+        }
+    }
+    __syncthreads();
+    const int m = min(scratch[2], k);
+    for (int i = tid; i < m; i += 256) {
+        const uint64_t ki = top[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += top[j] > ki ? 1 : 0;
+        cos_out[(size_t)q * k + rank] = key_score(ki);
+        id_out[(size_t)q * k + rank] = (int64_t)key_row(ki) + id_base;
+    }
+    for (int i = m + tid; i < k; i += 256) {
+        cos_out[(size_t)q * k + i] = -INFINITY;
+        id_out[(size_t)q * k + i] = -1;
+    }
+}
+
+uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace
+
+struct IvfState {
+    sqe_index* coarse = nullptr;       // flat index over the centroids
+    bool trained = false;
+    bool lists_dirty = true;
+    int64_t n_assigned = 0;            // rows of the base index that have an assignment
+    int max_len = 0;
+    Buf centroids, assign, order, offsets, counts, cursor;   // device
+    Buf qn, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
+    std::vector<int64_t> h_offsets;
+};
+
+static int ivf_assign_rows(sqe_index* base, IvfState* st, const float* rows_dev, int64_t n, int* assign_out,
+                           int64_t* ids64_out /* optional [n] */) {
+    // cosine top-1 of `rows_dev` against the centroids, in batches
+    sqe_ctx* ctx = index_ctx(base);
+    hipStream_t s = ctx_stream(ctx);
+    const int dim = index_dim(base);
+    const int64_t batch = 65536;
+    SQE_TRY(st->tmp_ids.ensure((size_t)std::min(batch, n) * 8));
+    SQE_TRY(st->tmp_cos.ensure((size_t)std::min(batch, n) * 4));
+    for (int64_t off = 0; off < n; off += batch) {
+        const int b = (int)std::min(batch, n - off);
+        SQE_TRY(sqe_index_search_device(st->coarse, rows_dev + (size_t)off * dim, b, 1, 0, st->tmp_cos.as<float>(),
+                                        st->tmp_ids.as<int64_t>()));
+        if (assign_out)
+            hipLaunchKernelGGL(ivf_store_assign_kernel, dim3((b + 255) / 256), dim3(256), 0, s, st->tmp_ids.as<int64_t>(),
+                               (int64_t)b, assign_out + off, (int*)nullptr);
+        if (ids64_out)
+            SQE_HIP(hipMemcpyAsync(ids64_out + off, st->tmp_ids.p, (size_t)b * 8, hipMemcpyDeviceToDevice, s));
+        SQE_HIP(hipGetLastError());
+    }
+    return SQE_OK;
+}
+
+int ivf_create(sqe_index* base, IvfState** out) {
+    IvfState* st = new (std::nothrow) IvfState;   // (struct defined above)
+    if (!st) return fail(SQE_ERR_OOM, "ivf: host allocation failed");
+    int rc = sqe_index_create(index_ctx(base), index_dim(base), SQE_INDEX_FLAT, 0, &st->coarse);
+    if (rc != SQE_OK) { delete st; return rc; }
+    *out = st;
+    return SQE_OK;
+}
+
+void ivf_destroy(IvfState* st) {
+    if (!st) return;
+    if (st->coarse) sqe_index_destroy(st->coarse);
+    delete st;
+}
+
+int ivf_rows_added(sqe_index* base, IvfState* st) {
+    // assign rows [n_assigned, rows) once the centroids exist
+    if (!st->trained) return SQE_OK;
+    const int64_t n = index_rows(base);
+    if (n <= st->n_assigned) return SQE_OK;
+    Buf grown;
+    SQE_TRY(grown.ensure((size_t)n * 4));
+    hipStream_t s = ctx_stream(index_ctx(base));
+    if (st->n_assigned > 0)
+        SQE_HIP(hipMemcpyAsync(grown.p, st->assign.p, (size_t)st->n_assigned * 4, hipMemcpyDeviceToDevice, s));
+    SQE_HIP(hipStreamSynchronize(s));
+    std::swap(grown.p, st->assign.p);
+    std::swap(grown.bytes, st->assign.bytes);
+    SQE_TRY(ivf_assign_rows(base, st, index_master(base) + (size_t)st->n_assigned * index_dim(base), n - st->n_assigned,
+                            st->assign.as<int>() + st->n_assigned, nullptr));
+    st->n_assigned = n;
+    st->lists_dirty = true;
+    return SQE_OK;
+}
+
+static int ivf_build_lists(sqe_index* base, IvfState* st) {
+    const int nlist = index_nlist(base);
+    const int64_t n = st->n_assigned;
+    hipStream_t s = ctx_stream(index_ctx(base));
+    SQE_TRY(st->counts.ensure((size_t)nlist * 4));
+    SQE_TRY(st->cursor.ensure((size_t)nlist * 4));
+    SQE_TRY(st->offsets.ensure((size_t)(nlist + 1) * 8));
+    SQE_TRY(st->order.ensure((size_t)std::max<int64_t>(n, 1) * 4));
+    SQE_HIP(hipMemsetAsync(st->counts.p, 0, (size_t)nlist * 4, s));
+    SQE_HIP(hipMemsetAsync(st->cursor.p, 0, (size_t)nlist * 4, s));
+    if (n > 0) hipLaunchKernelGGL(ivf_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st->assign.as<int>(), n, st->counts.as<int>());
+    std::vector<int> h_counts(nlist);
+    SQE_HIP(hipMemcpyAsync(h_counts.data(), st->counts.p, (size_t)nlist * 4, hipMemcpyDeviceToHost, s));
+    SQE_HIP(hipStreamSynchronize(s));
+    st->h_offsets.assign(nlist + 1, 0);
+    st->max_len = 0;
+    for (int i = 0; i < nlist; ++i) {
+        st->h_offsets[i + 1] = st->h_offsets[i] + h_counts[i];
+        st->max_len = std::max(st->max_len, h_counts[i]);
+    }
+    SQE_HIP(hipMemcpyAsync(st->offsets.p, st->h_offsets.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n > 0) hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st->assign.as<int>(), n,
+                                  st->offsets.as<int64_t>(), st->cursor.as<int>(), st->order.as<int>());
+    SQE_HIP(hipGetLastError());
+    SQE_HIP(hipStreamSynchronize(s));
+    st->lists_dirty = false;
+    return SQE_OK;
+}
+
+int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int iters, uint64_t seed) {
+    const int nlist = index_nlist(base), dim = index_dim(base);
+    if (n < nlist) return fail(SQE_ERR_INVALID, "sqe_index_train: need at least nlist training rows");
+    if (iters < 1) iters = 1;
+    sqe_ctx* ctx = index_ctx(base);
+    hipStream_t s = ctx_stream(ctx);
+    // normalised copy of the sample
+    Buf xs, pick, assign64;
+    SQE_TRY(xs.ensure((size_t)n * dim * 4));
+    SQE_TRY(launch_normalize_rows(x_dev, n, dim, xs.as<float>(), nullptr, dim, nullptr, nullptr, s));
+    // initial centroids: nlist distinct rows of the sample (seeded partial Fisher-Yates)
+    std::vector<int64_t> perm(n);
+    for (int64_t i = 0; i < n; ++i) perm[i] = i;
+    uint64_t rs = seed ^ 0x5eed5eedULL;
+    for (int i = 0; i < nlist; ++i) std::swap(perm[i], perm[i + (int64_t)(splitmix(rs) % (uint64_t)(n - i))]);
+    SQE_TRY(pick.ensure((size_t)nlist * 8));
+    SQE_HIP(hipMemcpyAsync(pick.p, perm.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, s));
+    SQE_TRY(st->centroids.ensure((size_t)nlist * dim * 4));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((nlist + 3) / 4), dim3(256), 0, s, xs.as<float>(), pick.as<int64_t>(), nlist, dim,
+                       st->centroids.as<float>());
+    SQE_HIP(hipGetLastError());
+    SQE_HIP(hipStreamSynchronize(s));      // perm is a host buffer
+    SQE_TRY(assign64.ensure((size_t)n * 8));
+    SQE_TRY(st->sums.ensure((size_t)nlist * dim * 4));
+    SQE_TRY(st->counts.ensure((size_t)nlist * 4));
+    for (int it = 0; it < iters; ++it) {
+        index_clear(st->coarse);
+        SQE_TRY(sqe_index_add_device(st->coarse, st->centroids.as<float>(), nlist));
+        SQE_TRY(ivf_assign_rows(base, st, xs.as<float>(), n, nullptr, assign64.as<int64_t>()));
+        SQE_HIP(hipMemsetAsync(st->sums.p, 0, (size_t)nlist * dim * 4, s));
+        SQE_HIP(hipMemsetAsync(st->counts.p, 0, (size_t)nlist * 4, s));
+        hipLaunchKernelGGL(kmeans_accum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, xs.as<float>(), assign64.as<int64_t>(), n,
+                           dim, st->sums.as<float>(), st->counts.as<int>());
+        hipLaunchKernelGGL(kmeans_finish_kernel, dim3((nlist + 3) / 4), dim3(256), 0, s, st->centroids.as<float>(), st->sums.as<float>(),
+                           st->counts.as<int>(), nlist, dim);
+        SQE_HIP(hipGetLastError());
+    }
+    index_clear(st->coarse);
+    SQE_TRY(sqe_index_add_device(st->coarse, st->centroids.as<float>(), nlist));
+    SQE_HIP(hipStreamSynchronize(s));
+    st->trained = true;
+    st->n_assigned = 0;                    // (re)assign everything stored so far
+    st->lists_dirty = true;
+    return ivf_rows_added(base, st);
+}
+
+int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, int nprobe, float* cos_out, int64_t* id_out) {
+    if (!st->trained) return fail(SQE_ERR_STATE, "sqe_index_search: IVF index is not trained (sqe_index_train)");
+    const int nlist = index_nlist(base), dim = index_dim(base);
+    if (nprobe <= 0) nprobe = 32;
+    nprobe = std::min(std::min(nprobe, nlist), MAX_KP);
+    sqe_ctx* ctx = index_ctx(base);
+    hipStream_t s = ctx_stream(ctx);
+    SQE_TRY(ivf_rows_added(base, st));
+    if (st->lists_dirty) SQE_TRY(ivf_build_lists(base, st));
+    const int max_len = std::max(st->max_len, 1);
+    SQE_TRY(st->qn.ensure((size_t)B * dim * 4));
+    SQE_TRY(st->probes_cos.ensure((size_t)B * nprobe * 4));
+    SQE_TRY(st->probes_ids.ensure((size_t)B * nprobe * 8));
+    SQE_TRY(st->lcount.ensure((size_t)nlist * 4));
+    SQE_TRY(st->lq.ensure((size_t)nlist * B * 4));
+    SQE_TRY(st->pair_scores.ensure((size_t)B * nprobe * max_len * 4));
+    SQE_TRY(launch_normalize_rows(q_dev, B, dim, st->qn.as<float>(), nullptr, dim, nullptr, nullptr, s));
+    // S5: coarse quantise
+    SQE_TRY(sqe_index_search_device(st->coarse, st->qn.as<float>(), B, nprobe, 0, st->probes_cos.as<float>(), st->probes_ids.as<int64_t>()));
+    SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)nlist * 4, s));
+    hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
+                       st->lcount.as<int>(), st->lq.as<int>(), B);
+    // S6: list scan
+    hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, index_master(base), st->qn.as<float>(), st->order.as<int>(),
+                       st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                       st->pair_scores.as<float>());
+    hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
+                       st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, index_id_base(base), cos_out, id_out);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+void ivf_invalidate(IvfState* st) { st->n_assigned = 0; st->lists_dirty = true; }
+sqe_index* ivf_coarse(IvfState* st) { return st->coarse; }
+
+// introspection for tests / tools: centroids and assignments as stored
+int ivf_export(sqe_index* base, IvfState* st, float* centroids_host, int32_t* assign_host) {
+    if (!st->trained) return fail(SQE_ERR_STATE, "ivf export: not trained");
+    hipStream_t s = ctx_stream(index_ctx(base));
+    SQE_TRY(ivf_rows_added(base, st));
+    if (centroids_host)
+        SQE_HIP(hipMemcpyAsync(centroids_host, index_master(st->coarse), (size_t)index_nlist(base) * index_dim(base) * 4,
+                               hipMemcpyDeviceToHost, s));
+    if (assign_host && st->n_assigned > 0)
+        SQE_HIP(hipMemcpyAsync(assign_host, st->assign.p, (size_t)st->n_assigned * 4, hipMemcpyDeviceToHost, s));
+    SQE_HIP(hipStreamSynchronize(s));
+    return SQE_OK;
+}
+
+}  // namespace sqe

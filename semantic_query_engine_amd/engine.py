@@ -162,6 +162,22 @@ class VectorIndex:
             N.check(self.lib.sqe_index_get_rows(self.handle, rows.ctypes.data, rows.shape[0], out.ctypes.data))
         return out
 
+    # -- IVF-flat only
+    def train(self, x: np.ndarray, iters: int = 20, seed: int = 0) -> None:
+        """Spherical k-means on the sample ``x`` (host array), then (re)assignment of stored rows."""
+        x = _f32(x)
+        N.check(self.lib.sqe_index_train(self.handle, x.ctypes.data, x.shape[0], iters, seed))
+
+    def train_device(self, ptr: int, n: int, iters: int = 20, seed: int = 0) -> None:
+        N.check(self.lib.sqe_index_train_device(self.handle, ptr, n, iters, seed))
+
+    def ivf_export(self, nlist: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (centroids float32 [nlist, dim], list id of every stored row int32 [count])."""
+        cen = np.empty((nlist, self.dim), np.float32)
+        asg = np.empty(len(self), np.int32)
+        N.check(self.lib.sqe_index_ivf_export(self.handle, cen.ctypes.data, asg.ctypes.data))
+        return cen, asg
+
     def search(self, q: np.ndarray, k: int, nprobe: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         """-> (cos [B,k] float32, ids [B,k] int64), best first, ties to the lowest id,
         (-inf, -1) padded."""

@@ -1,0 +1,59 @@
+"""IVF-flat (train / add / search) against the oracle's IVF semantics.  GPU only."""
+import numpy as np
+import pytest
+
+from oracle import retrieval as R
+from tests.gpu_util import assert_topk_matches
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustered(n, d, ncl, seed, sigma=0.3):
+    rng = np.random.default_rng(seed)
+    cen = rng.standard_normal((ncl, d)).astype(np.float32)
+    lab = rng.integers(0, ncl, n)
+    x = cen[lab] + sigma * rng.standard_normal((n, d)).astype(np.float32) * np.sqrt(1.0)
+    return x.astype(np.float32), cen
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from semantic_query_engine_amd import Context
+    return Context(0)
+
+
+def test_ivf_matches_oracle_and_recall(ctx):
+    from semantic_query_engine_amd import INDEX_IVF_FLAT, VectorIndex
+    n, d, nlist, k = 30000, 128, 64, 10
+    x, cen = _clustered(n, d, 200, seed=1)
+    rng = np.random.default_rng(2)
+    q = (x[rng.integers(0, n, 48)] + 0.2 * rng.standard_normal((48, d))).astype(np.float32)
+    idx = VectorIndex(ctx, d, INDEX_IVF_FLAT, nlist)
+    with pytest.raises(Exception):
+        idx.search(q, k)                                  # not trained yet
+    idx.add(x[:10000])                                    # rows added before training are assigned by train()
+    idx.train(x[:20000], iters=8, seed=3)
+    idx.add(x[10000:])                                    # rows added after training are assigned on add
+    assert len(idx) == n
+    centroids, assign = idx.ivf_export(nlist)
+    assert assign.shape == (n,) and assign.min() >= 0 and assign.max() < nlist
+    assert np.allclose(np.linalg.norm(centroids, axis=1), 1.0, atol=1e-5)
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    # every row sits in the list of its best centroid (ties within fp32 rounding excepted)
+    best = (xn.astype(np.float64) @ centroids.astype(np.float64).T)
+    gap = best.max(1) - best[np.arange(n), assign]
+    assert np.all(gap < 2e-6)
+    for nprobe in (1, 8, 64):
+        cos, ids = idx.search(q, k, nprobe=nprobe)
+        ref_cos, ref_ids = R.ivf_search(xn, qn, centroids, assign, k, nprobe)
+        assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
+    # nprobe = nlist is the exact search; nprobe = 8 of 64 already recalls >= 0.95 on clustered data
+    exact_cos, exact_ids = R.exact_topk(xn, qn, k)
+    cos, ids = idx.search(q, k, nprobe=nlist)
+    assert R.recall_at_k(ids, exact_ids) == 1.0
+    cos8, ids8 = idx.search(q, k, nprobe=8)
+    assert R.recall_at_k(ids8, exact_ids) >= 0.95
+    # overwriting rows re-assigns them
+    idx.update(np.array([5]), q[:1] * 3.0)
+    cos, ids = idx.search(q[:1], 1, nprobe=4)
+    assert ids[0, 0] == 5 and abs(cos[0, 0] - 1.0) < 1e-5
