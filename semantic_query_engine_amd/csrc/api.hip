@@ -144,7 +144,7 @@ struct sqe_index {
     DevBuf dbg;                    // 8 x u64 debug counters (SQE_DBG bit 32)
     DevBuf resid_max;              // u32 float bits: max over rows of || x_hat - bf16(x_hat) ||
     DevBuf q_resid;                // [B] the same per query
-    DevBuf unc;                    // int count | int list[B] | float thr[B]  (queue of uncertified queries)
+    DevBuf unc;                    // int count (16 B) | float collect_thr[b_pad]
     DevBuf fb_keys, fb_cnt;        // exact-rescan collection buffers
     int certify = 1;               // run the exactness certificate + fp32 rescan fallback
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
@@ -490,7 +490,7 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     const bool certify = idx->certify && idx->n > 0;
     SQE_TRY(idx->q_resid.ensure((size_t)B * 4));
     if (certify) {
-        SQE_TRY(idx->unc.ensure(16 + (size_t)B * 8));
+        SQE_TRY(idx->unc.ensure(16 + (size_t)plan.b_pad * 4));
         SQE_TRY(idx->fb_keys.ensure((size_t)B * EXACT_CAP * 8));
         SQE_TRY(idx->fb_cnt.ensure((size_t)B * 4));
     }
@@ -513,6 +513,7 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
         a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
         a.dbg_counters = nullptr;
+        a.collect_thr = nullptr; a.collect_keys = nullptr; a.collect_cnt = nullptr; a.unc_count = nullptr;
         {
             static const bool want = [] { const char* e = getenv("SQE_DBG"); return e && (atoi(e) & 32); }();
             if (want) {
@@ -533,19 +534,28 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         s.master = idx->master; s.qn = idx->qn.as<float>(); s.K = K; s.B = B; s.k = k;
         s.cos_out = cos_out_dev; s.id_out = id_out_dev; s.id_base = idx->id_base;
         int* unc_count = certify ? idx->unc.as<int>() : nullptr;
-        int* unc_list = certify ? idx->unc.as<int>() + 4 : nullptr;
-        float* unc_thr = certify ? reinterpret_cast<float*>(idx->unc.as<int>() + 4 + B) : nullptr;
+        float* collect_thr = certify ? reinterpret_cast<float*>(idx->unc.as<int>() + 4) : nullptr;
         s.q_resid = certify ? idx->q_resid.as<float>() : nullptr;
         s.db_resid_max = certify ? idx->resid_max.as<uint32_t>() : nullptr;
-        s.unc_count = unc_count; s.unc_list = unc_list; s.unc_thr = unc_thr;
+        s.unc_count = unc_count; s.collect_thr = collect_thr;
         SQE_TRY(launch_select_rescore(s, c->stream));
         if (certify) {
+            // second pass for the queries whose certificate failed (both kernels return at once
+            // when there are none): collect every row that can still be in the exact top-k ...
+            ScanArgs a;
+            a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
+            a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
+            a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
+            a.dbg_counters = nullptr;
+            a.collect_thr = collect_thr; a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
+            a.unc_count = unc_count;
+            SQE_TRY(launch_scan_collect(plan, a, c->stream));
+            // ... and re-score them in fp32
             ExactArgs e;
-            e.master = idx->master; e.qn = idx->qn.as<float>(); e.n_rows = idx->n; e.K = K; e.B = B; e.k = k;
-            e.unc_count = unc_count; e.unc_list = unc_list; e.unc_thr = unc_thr;
-            e.keys = idx->fb_keys.as<uint64_t>(); e.key_cnt = idx->fb_cnt.as<int>();
+            e.master = idx->master; e.qn = idx->qn.as<float>(); e.K = K; e.B = B; e.k = k;
+            e.collect_thr = collect_thr; e.keys = idx->fb_keys.as<uint64_t>(); e.key_cnt = idx->fb_cnt.as<int>();
             e.cos_out = cos_out_dev; e.id_out = id_out_dev; e.id_base = idx->id_base;
-            SQE_TRY(launch_exact_rescan(e, c->cu_count, c->stream));
+            SQE_TRY(launch_collect_rescore(e, c->stream));
             c->last_unc_count = unc_count;
         }
     }

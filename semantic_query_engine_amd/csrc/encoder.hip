@@ -581,18 +581,19 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
     const int H = c.hidden, I = c.inter;
     const int T = B * S;
     const int t_pad = (T + 255) / 256 * 256;
+    // +64 rows: the attention kernel stages whole 64-key tiles, which may run past the last sequence
     if (t_pad > enc->t_cap) {
-        SQE_TRY(enc->x.alloc((size_t)t_pad * H * 2));
-        SQE_TRY(enc->x1.alloc((size_t)t_pad * H * 2));
-        SQE_TRY(enc->att.alloc((size_t)t_pad * H * 2));
-        SQE_TRY(enc->qkv.alloc((size_t)t_pad * 3 * H * 2));
-        SQE_TRY(enc->hbuf.alloc((size_t)t_pad * I * 2));
+        SQE_TRY(enc->x.alloc((size_t)(t_pad + 64) * H * 2));
+        SQE_TRY(enc->x1.alloc((size_t)(t_pad + 64) * H * 2));
+        SQE_TRY(enc->att.alloc((size_t)(t_pad + 64) * H * 2));
+        SQE_TRY(enc->qkv.alloc((size_t)(t_pad + 64) * 3 * H * 2));
+        SQE_TRY(enc->hbuf.alloc((size_t)(t_pad + 64) * I * 2));
         SQE_TRY(enc->pre.alloc((size_t)t_pad * H * 4));
-        SQE_HIP(hipMemsetAsync(enc->x.p, 0, (size_t)t_pad * H * 2, st));
-        SQE_HIP(hipMemsetAsync(enc->x1.p, 0, (size_t)t_pad * H * 2, st));
-        SQE_HIP(hipMemsetAsync(enc->att.p, 0, (size_t)t_pad * H * 2, st));
-        SQE_HIP(hipMemsetAsync(enc->qkv.p, 0, (size_t)t_pad * 3 * H * 2, st));
-        SQE_HIP(hipMemsetAsync(enc->hbuf.p, 0, (size_t)t_pad * I * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->x.p, 0, (size_t)(t_pad + 64) * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->x1.p, 0, (size_t)(t_pad + 64) * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->att.p, 0, (size_t)(t_pad + 64) * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->qkv.p, 0, (size_t)(t_pad + 64) * 3 * H * 2, st));
+        SQE_HIP(hipMemsetAsync(enc->hbuf.p, 0, (size_t)(t_pad + 64) * I * 2, st));
         enc->t_cap = t_pad;
     }
     const int cus = ctx_cu_count(enc->ctx);

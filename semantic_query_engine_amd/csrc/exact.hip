@@ -1,101 +1,60 @@
-// exact.hip -- exact fp32 rescan for queries the bf16 scan could not certify (select.hip).
+// exact.hip -- certified fallback, second half: fp32 re-scoring of the rows the collect pass
+// gathered for a query whose certificate failed (select.hip, scan.hip COLLECT mode).
 //
-// For a queued query the re-scored candidates give a LOWER BOUND t of its true k-th best cosine
-// (k real rows reach it).  The exact top-k is therefore among the rows whose fp32 cosine is >= t:
-// one streaming pass over the fp32 master computes every row's cosine against up to 8 queued
-// queries at a time and appends the rows that reach the bound; the few collected keys are then
-// ordered exactly (cosine desc, row id asc).  HBM-bound (N * D * 4 bytes per group of 8 queries);
-// runs only when the certificate fails -- the kernel exits at once when nothing is queued.
+// Every row that can belong to the exact top-k has a bf16 scan score >= (t - eps) and was appended
+// to the query's buffer; here each collected row is re-scored in fp32 against the master, the k
+// best keys (cosine desc, row id asc) are selected and written over the uncertified result.
+// One workgroup per query; it returns at once for certified queries (collect_thr == +inf).
 #include "kernels.h"
 
 namespace sqe {
 
 namespace {
 
-constexpr int QG_MAX = 8;                 // queries per pass
-constexpr int QLDS_FLOATS = 8192;         // 32 KiB of LDS for the query group
-
-struct ExactKernelArgs {
+struct RescoreArgs {
     const float* master;
     const float* qn;
-    int64_t n_rows;
     int K, B, k;
-    const int* unc_count;
-    const int* unc_list;
-    const float* unc_thr;
+    const float* collect_thr;
     uint64_t* keys;
-    int* key_cnt;
+    const int* key_cnt;
     float* cos_out;
     int64_t* id_out;
     int64_t id_base;
 };
 
-__global__ __launch_bounds__(256) void exact_rescan_kernel(ExactKernelArgs p) {
-    __shared__ __attribute__((aligned(16))) float sq[QLDS_FLOATS];
-    __shared__ float sthr[QG_MAX];
-    const int n_unc = min(*p.unc_count, p.B);
-    if (n_unc <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qg = min(QG_MAX, QLDS_FLOATS / p.K);             // queries per pass (>= 1: K <= 8192)
-    const int nvec = p.K >> 2;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * 4;
-    for (int g0 = 0; g0 < n_unc; g0 += qg) {
-        const int gq = min(qg, n_unc - g0);
-        __syncthreads();
-        for (int i = tid; i < gq * p.K; i += 256) {
-            const int j = i / p.K, d = i - j * p.K;
-            sq[i] = p.qn[(size_t)p.unc_list[g0 + j] * p.K + d];
-        }
-        if (tid < gq) sthr[tid] = p.unc_thr[g0 + tid];
-        __syncthreads();
-        for (int64_t row = wave_id; row < p.n_rows; row += wave_stride) {
-            const float4* rv = reinterpret_cast<const float4*>(p.master + (size_t)row * p.K);
-            float acc[QG_MAX];
-#pragma unroll
-            for (int j = 0; j < QG_MAX; ++j) acc[j] = 0.f;
-            for (int v = lane; v < nvec; v += 64) {
-                const float4 a = rv[v];
-#pragma unroll
-                for (int j = 0; j < QG_MAX; ++j) {
-                    if (j < gq) {
-                        const float4 b = *reinterpret_cast<const float4*>(&sq[j * p.K + v * 4]);
-                        acc[j] = fmaf(a.x, b.x, acc[j]); acc[j] = fmaf(a.y, b.y, acc[j]);
-                        acc[j] = fmaf(a.z, b.z, acc[j]); acc[j] = fmaf(a.w, b.w, acc[j]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < QG_MAX; ++j) {
-                if (j < gq) {
-                    const float s = wave_sum(acc[j]) + 0.0f;
-                    if (lane == 0 && s >= sthr[j]) {
-                        const int slot = atomicAdd(&p.key_cnt[g0 + j], 1);
-                        if (slot < EXACT_CAP) p.keys[(size_t)(g0 + j) * EXACT_CAP + slot] = make_key(s, (uint32_t)row);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// one workgroup per queue position: exact order of the collected keys, top-k written over the
-// uncertified result of that query
-__global__ __launch_bounds__(256) void exact_finalize_kernel(ExactKernelArgs p) {
+__global__ __launch_bounds__(256) void collect_rescore_kernel(RescoreArgs p) {
     __shared__ int hist[256];
     __shared__ int scratch[4];
     __shared__ uint64_t top[MAX_KP];
-    const int pos = blockIdx.x;
-    const int n_unc = min(*p.unc_count, p.B);
-    if (pos >= n_unc) return;
-    const int tid = threadIdx.x;
-    const int q = p.unc_list[pos];
-    const int n = min(p.key_cnt[pos], EXACT_CAP);
-    const uint64_t* keys = p.keys + (size_t)pos * EXACT_CAP;
+    const int q = blockIdx.x;
+    if (p.collect_thr[q] == INFINITY) return;            // certified: result already final
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // More rows inside the error band than the buffer holds (thousands of near-identical vectors):
+    // the collected set is incomplete, so the first-pass result stands -- it is still ordered by the
+    // scan's own (score, lowest id) keys, which is the right answer when those rows are duplicates.
+    if (p.key_cnt[q] > EXACT_CAP) return;
+    const int n = p.key_cnt[q];
+    uint64_t* keys = p.keys + (size_t)q * EXACT_CAP;
+    // fp32 re-score, one wave per collected row
+    const float4* qv = reinterpret_cast<const float4*>(p.qn + (size_t)q * p.K);
+    const int nvec = p.K >> 2;
+    for (int e = wave; e < n; e += 4) {
+        const uint32_t row = key_row(keys[e]);
+        const float4* rv = reinterpret_cast<const float4*>(p.master + (size_t)row * p.K);
+        float s = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            const float4 a = rv[v], b = qv[v];
+            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+        s = wave_sum(s) + 0.0f;
+        if (lane == 0) keys[e] = make_key(s, row);
+    }
+    __syncthreads();
     // k-th largest key by MSB-first byte-wise radix select (keys are unique)
     uint64_t prefix = 0;
     int remaining = p.k;
-    bool all = n <= p.k;
+    const bool all = n <= p.k;
     for (int byte = 7; byte >= 0 && !all; --byte) {
         hist[tid] = 0;
         __syncthreads();
@@ -111,8 +70,8 @@ __global__ __launch_bounds__(256) void exact_finalize_kernel(ExactKernelArgs p) 
                 if (cum + hist[bin] >= remaining) break;
                 cum += hist[bin];
             }
-            scratch[0] = bin;
-            scratch[1] = remaining - cum;
+            scratch[0] = bin < 0 ? 0 : bin;
+            scratch[1] = bin < 0 ? remaining : remaining - cum;
         }
         __syncthreads();
         prefix |= ((uint64_t)scratch[0] << shift);
@@ -148,19 +107,13 @@ __global__ __launch_bounds__(256) void exact_finalize_kernel(ExactKernelArgs p) 
 
 }  // namespace
 
-int launch_exact_rescan(const ExactArgs& a, int cu_count, hipStream_t stream) {
-    if (a.B <= 0 || a.n_rows <= 0) return SQE_OK;
-    if (a.K % 4 != 0 || a.K > QLDS_FLOATS) return fail(SQE_ERR_INVALID, "exact rescan: dim must be a multiple of 4, <= 8192");
-    ExactKernelArgs p;
-    p.master = a.master; p.qn = a.qn; p.n_rows = a.n_rows; p.K = a.K; p.B = a.B; p.k = a.k;
-    p.unc_count = a.unc_count; p.unc_list = a.unc_list; p.unc_thr = a.unc_thr;
+int launch_collect_rescore(const ExactArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return SQE_OK;
+    if (a.K % 4 != 0) return fail(SQE_ERR_INVALID, "collect rescore: dim must be a multiple of 4");
+    RescoreArgs p;
+    p.master = a.master; p.qn = a.qn; p.K = a.K; p.B = a.B; p.k = a.k; p.collect_thr = a.collect_thr;
     p.keys = a.keys; p.key_cnt = a.key_cnt; p.cos_out = a.cos_out; p.id_out = a.id_out; p.id_base = a.id_base;
-    int grid = cu_count * 4;
-    const int64_t need = (a.n_rows + 3) / 4;
-    if (grid > need) grid = (int)need;
-    hipLaunchKernelGGL(exact_rescan_kernel, dim3(grid), dim3(256), 0, stream, p);
-    SQE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(exact_finalize_kernel, dim3(a.B), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(collect_rescore_kernel, dim3(a.B), dim3(256), 0, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

@@ -50,11 +50,19 @@ struct ScanArgs {
     int* cand_cnt;        // [n_chunks, b_pad]
     uint32_t* gmax;       // [b_pad, ngroups, GMAX_COLS], zeroed before the launch
     unsigned long long* dbg_counters;   // null unless SQE_DBG has bit 32
+    // collect pass (launch_scan_collect): see ExactArgs
+    const float* collect_thr;
+    uint64_t* collect_keys;
+    int* collect_cnt;
+    const int* unc_count;
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless
 // unless the environment sets SQE_SCAN_P8=1 it uses the two-stage form (measured slightly faster).
 int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
+// second pass for uncertified queries: same scan, fixed thresholds args.collect_thr, every row at or
+// above its query's threshold goes to args.collect_keys; exits at once when *args.unc_count == 0
+int launch_scan_collect(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 
 // ------------------------------------------------------------------ select + rescore (S3+S4)
 struct SelectArgs {
@@ -71,29 +79,29 @@ struct SelectArgs {
     // best score any unseen row could have is queued for the exact fp32 rescan (exact.hip)
     const float* q_resid;          // [B]  || q_hat - bf16(q_hat) ||
     const uint32_t* db_resid_max;  // max over rows of || x_hat - bf16(x_hat) || (float bits)
-    int* unc_count;                // number of queued queries
-    int* unc_list;                 // [B] queued query ids
-    float* unc_thr;                // [B] (indexed by queue position) lower bound of the k-th best true cosine
+    int* unc_count;                // number of uncertified queries
+    float* collect_thr;            // [b_pad] per query: +inf if certified, else (k-th true cosine) - eps
 };
 int launch_select_rescore(const SelectArgs& args, hipStream_t stream);
 
-// ------------------------------------------------------------------ exact fp32 rescan (fallback)
-constexpr int EXACT_CAP = 4096;    // keys collected per queued query
+// ------------------------------------------------------------------ certified fallback
+// For a query whose certificate failed, select.hip leaves collect_thr[q] = t - eps (t = lower bound
+// of the true k-th cosine, eps = bf16 error bound): every row that can be in the exact top-k has a
+// bf16 scan score >= that.  launch_scan_collect gathers those rows, launch_collect_rescore re-scores
+// them in fp32 and writes the exact top-k over the uncertified result.
+constexpr int EXACT_CAP = 4096;    // keys collected per uncertified query
 struct ExactArgs {
     const float* master;   // [n_rows, K]
     const float* qn;       // [B, K] normalised queries
-    int64_t n_rows;
     int K, B, k;
-    const int* unc_count;
-    const int* unc_list;
-    const float* unc_thr;
+    const float* collect_thr;   // [B]
     uint64_t* keys;        // [B, EXACT_CAP]
-    int* key_cnt;          // [B], zeroed before the launch
+    const int* key_cnt;    // [B]
     float* cos_out;
     int64_t* id_out;
     int64_t id_base;
 };
-int launch_exact_rescan(const ExactArgs& args, int cu_count, hipStream_t stream);
+int launch_collect_rescore(const ExactArgs& args, hipStream_t stream);
 
 // merge of [P,B,k] partial results (multi-GPU all-gather output)
 int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,

@@ -115,10 +115,22 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     f.per_wave = PER_WAVE;
     f.dbg_no_slow = (p.dbg & 16) != 0;
     f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
+    const bool collect = p.collect_thr != nullptr;      // second pass for uncertified queries
+    if (collect && *p.unc_count == 0) return;           // nothing failed its certificate
+    f.collect_keys = collect ? p.collect_keys + (size_t)q0 * EXACT_CAP : nullptr;
+    f.collect_cnt = collect ? p.collect_cnt + q0 : nullptr;
     for (int i = tid; i < BN; i += THREADS) {
         const bool live = (q0 + i) < p.B;
-        f.thr_key[i] = live ? 0ull : ~0ull;
-        f.thr_s[i] = live ? -INFINITY : INFINITY;
+        float ts = live ? -INFINITY : INFINITY;
+        uint64_t tk = live ? 0ull : ~0ull;
+        if (collect && live) {
+            // fixed threshold: every row whose scan score is >= collect_thr is collected
+            ts = p.collect_thr[q0 + i];
+            const uint32_t o = f32_orderable(ts);
+            tk = ts == INFINITY ? ~0ull : ((uint64_t)o << 32) - 1ull;
+        }
+        f.thr_key[i] = tk;
+        f.thr_s[i] = ts;
         f.cnt[i] = 0;
         f.cmax[i] = 0u;
     }
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 
     // Tile sequence: entry 0 = first tile in BOOT mode, entries 1..nt-1 the other tiles, entry
     // nt = the first tile again, normally.  (nt == 0: nothing.)
-    const int n_entries = nt > 0 ? nt + 1 : 0;
+    const int n_entries = nt > 0 ? nt + (collect ? 0 : 1) : 0;   // collect mode: every tile once, no boot entry
     const int total_stages = n_entries * KS;
     const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ldB;
     const char* dbbase = reinterpret_cast<const char*>(p.db);
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             // Bound refresh schedule: entry 1 fetches every slice back to back from K step KS/4 on
             // (after every chunk has published its boot maxima); later one slice per tile.
             const bool want = entry == 1 ? (ks >= KS / 4 && refresh_ctr < NSLICE) : (entry > 1 && ks == 0);
-            if (want && p.gshift >= 0) {
+            if (want && p.gshift >= 0 && !collect) {
                 refresh_pending = refresh_ctr % NSLICE;
                 ++refresh_ctr;
                 refresh_issue(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 
         if (ks == KS - 1) {
             const int64_t row0 = (int64_t)tile_of(entry) * BM;
-            if (entry == 0) {
+            if (entry == 0 && !collect) {
                 filter_boot<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
                 __syncthreads();
                 publish_cmax(f, wave * PER_WAVE, PER_WAVE, lane);
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         __syncthreads();   // next stage landed (vmcnt(0)); everyone done with `cur`; state settled
     }
 
+    if (collect) return;                                 // keys went straight to the per-query buffers
     // final: every list down to <= kp entries, counts published
     compact_owned(f, wave * PER_WAVE, PER_WAVE, p.kp + 1, p.kp, lane);
     __syncthreads();
@@ -225,10 +238,14 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 }
 
 template <int WM, int WN, int FM, int FN>
-int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
+int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool collect = false) {
     constexpr int BN = WN * FN * 16;
     constexpr int LDS = 2 * (SCAN_BM + BN) * ROW_BYTES + FilterLds<BN>::BYTES;
     ScanKernelArgs k = make_kernel_args(plan, a);
+    if (collect) {
+        k.collect_thr = a.collect_thr; k.collect_keys = a.collect_keys; k.collect_cnt = a.collect_cnt;
+        k.unc_count = a.unc_count;
+    }
     auto kern = scan_bf16_kernel<WM, WN, FM, FN>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -258,6 +275,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
         k.dbg = dbg;
     }
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax; k.dbg_counters = a.dbg_counters;
+    k.collect_thr = nullptr; k.collect_keys = nullptr; k.collect_cnt = nullptr; k.unc_count = nullptr;
     return k;
 }
 
@@ -279,6 +297,13 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     // global bound: 64 >> gshift groups, each contributing one distinct row, must be >= kp
     p.gshift = kp <= 16 ? 2 : kp <= 32 ? 1 : kp <= 64 ? 0 : -1;
     return p;
+}
+
+int launch_scan_collect(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
+    if (!a.collect_thr || !a.collect_keys || !a.collect_cnt || !a.unc_count)
+        return fail(SQE_ERR_INVALID, "scan collect: missing buffers");
+    if (plan.bn == 256) return launch_cfg<2, 4, 8, 4>(plan, a, stream, true);
+    return launch_cfg<8, 1, 2, 4>(plan, a, stream, true);
 }
 
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     f.per_wave = 32;
     f.dbg_no_slow = (p.dbg & 16) != 0;
     f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
+    f.collect_keys = nullptr; f.collect_cnt = nullptr;
     for (int i = tid; i < BN8; i += SCAN_THREADS) {
         const bool live = (q0 + i) < p.B;
         f.thr_key[i] = live ? 0ull : ~0ull;

@@ -55,6 +55,12 @@ struct ScanKernelArgs {
     int* cand_cnt;
     uint32_t* gmax;      // [b_pad/64][ngroups][GMAX_COLS][64] orderable scores, 0 = nothing yet
     unsigned long long* dbg_counters;   // [8] or null: 0 appends, 1 slow-path wave entries, 2 compactions
+    // COLLECT mode (second pass for queries whose certificate failed): fixed per-query thresholds,
+    // every row at or above them is appended to a per-query global buffer; no lists, no bound exchange
+    const float* collect_thr;    // [b_pad] or null (normal mode); +inf = query not collected
+    uint64_t* collect_keys;      // [B][EXACT_CAP]
+    int* collect_cnt;            // [B]
+    const int* unc_count;        // the pass exits at once when this is 0
 };
 
 // LDS block of the filter state for a query block of BN queries (after the staging area).
@@ -84,6 +90,8 @@ struct Filter {
     int gstride;           // ngroups * GMAX_COLS * 64: uint32 elements between consecutive query slices
     bool dbg_no_slow;      // timing experiments only: pretend no row survives
     unsigned long long* dbg_counters;
+    uint64_t* collect_keys;    // COLLECT mode: per-query global buffers of this query block, else null
+    int* collect_cnt;
 };
 
 // host: kernel argument block from a plan (scan.hip)
@@ -225,6 +233,11 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                             if (row < f.n_rows && qcol < f.q_live) {
                                 const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
                                 if (key > f.thr_key[qcol]) {
+                                    if (f.collect_keys) {
+                                        const int gslot = atomicAdd(&f.collect_cnt[qcol], 1);
+                                        if (gslot < EXACT_CAP) f.collect_keys[(size_t)qcol * EXACT_CAP + gslot] = key;
+                                        continue;
+                                    }
                                     const int slot = atomicAdd(&f.cnt[qcol], 1);
                                     if (f.dbg_counters) atomicAdd(&f.dbg_counters[0], 1ull);
                                     f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;

@@ -26,8 +26,7 @@ struct SelectKernelArgs {
     const float* q_resid;
     const uint32_t* db_resid_max;
     int* unc_count;
-    int* unc_list;
-    float* unc_thr;
+    float* collect_thr;
 };
 
 // MSB-first byte-wise radix select of the `kth` largest key among the valid candidates of
@@ -144,16 +143,19 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
     // so no unseen row can reach score(T) + eps.  T == 0: every row of the index is a candidate.
     if (p.unc_count) {
         __syncthreads();
-        if (tid == 0 && T != 0ull) {
-            const float dq = p.q_resid[q];
-            const float dx = __uint_as_float(*p.db_resid_max);
-            const float eps = (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + 2.0e-4f;
-            const bool certified = m >= p.k && kth_score > key_score(T) + eps;
-            if (!certified) {
-                const int slot = atomicAdd(p.unc_count, 1);
-                p.unc_list[slot] = q;
-                p.unc_thr[slot] = m >= p.k ? kth_score : -INFINITY;
+        if (tid == 0) {
+            float thr = INFINITY;                    // certified: nothing to collect
+            if (T != 0ull) {
+                const float dq = p.q_resid[q];
+                const float dx = __uint_as_float(*p.db_resid_max);
+                const float eps = (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + 2.0e-4f;
+                const bool certified = m >= p.k && kth_score > key_score(T) + eps;
+                if (!certified) {
+                    atomicAdd(p.unc_count, 1);
+                    thr = (m >= p.k ? kth_score : -1.0f) - eps;
+                }
             }
+            p.collect_thr[q] = thr;
         }
     }
 }
@@ -213,8 +215,7 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.n_chunks = a.n_chunks; k.b_pad = a.b_pad; k.kp = a.kp;
     k.master = a.master; k.qn = a.qn; k.K = a.K; k.B = a.B; k.k = a.k;
     k.cos_out = a.cos_out; k.id_out = a.id_out; k.id_base = a.id_base;
-    k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max; k.unc_count = a.unc_count; k.unc_list = a.unc_list;
-    k.unc_thr = a.unc_thr;
+    k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max; k.unc_count = a.unc_count; k.collect_thr = a.collect_thr;
     hipLaunchKernelGGL(select_rescore_kernel, dim3(a.B), dim3(SEL_THREADS), 0, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
