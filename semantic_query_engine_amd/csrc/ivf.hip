@@ -166,6 +166,44 @@ __global__ __launch_bounds__(256) void ivf_list_scan_kernel(const float* __restr
             sq[i] = qn[(size_t)(spair[j] / nprobe) * K + d];
         }
         __syncthreads();
+        if (K == 1024) {
+            // fast path for the reference dimension: two rows per wave in flight, all eight 1-KiB
+            // row loads issued before the first use, query fragments read once for both rows
+            for (int i = wave * 2; i < len; i += 8) {
+                const bool two = i + 1 < len;
+                const float4* r0 = reinterpret_cast<const float4*>(master + (size_t)order[off + i] * 1024);
+                const float4* r1 = reinterpret_cast<const float4*>(master + (size_t)order[off + (two ? i + 1 : i)] * 1024);
+                float4 a0[4], a1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { a0[t] = r0[lane + 64 * t]; a1[t] = r1[lane + 64 * t]; }
+                float acc0[IVF_QG], acc1[IVF_QG];
+#pragma unroll
+                for (int j = 0; j < IVF_QG; ++j) {
+                    acc0[j] = 0.f; acc1[j] = 0.f;
+                    if (j < gq) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float4 b = *reinterpret_cast<const float4*>(&sq[j * 1024 + (lane + 64 * t) * 4]);
+                            acc0[j] = fmaf(a0[t].x, b.x, acc0[j]); acc0[j] = fmaf(a0[t].y, b.y, acc0[j]);
+                            acc0[j] = fmaf(a0[t].z, b.z, acc0[j]); acc0[j] = fmaf(a0[t].w, b.w, acc0[j]);
+                            acc1[j] = fmaf(a1[t].x, b.x, acc1[j]); acc1[j] = fmaf(a1[t].y, b.y, acc1[j]);
+                            acc1[j] = fmaf(a1[t].z, b.z, acc1[j]); acc1[j] = fmaf(a1[t].w, b.w, acc1[j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < IVF_QG; ++j) {
+                    if (j < gq) {
+                        const float s0 = wave_sum(acc0[j]) + 0.0f, s1 = wave_sum(acc1[j]) + 0.0f;
+                        if (lane == 0) {
+                            pair_scores[(size_t)spair[j] * max_len + i] = s0;
+                            if (two) pair_scores[(size_t)spair[j] * max_len + i + 1] = s1;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int i = wave; i < len; i += 4) {
             const float4* rv = reinterpret_cast<const float4*>(master + (size_t)order[off + i] * K);
             float acc[IVF_QG];
