@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage: scripts_pmc.sh <tag> <extra env assignments...>   (run on the GPU box from repo root)
+# usage: tools/pmc_scan.sh <tag> <extra env assignments...>   (run on the GPU box from repo root)
 # Collects per-kernel PMC counters for the scan kernel in separate passes (gfx950: FETCH_SIZE
 # needs its own pass; SQ counters 8 per pass).
 tag=$1; shift
 export TMPDIR=/tmp
-args="--steps 3 --warmup 1 --rows 2000000 --no-cpu-baseline --recall-queries 8"
+args="--steps 3 --warmup 1 --rows ${PMC_ROWS:-10000000} --no-cpu-baseline --recall-queries 8"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
