@@ -60,7 +60,7 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(tile + r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
-template <int WM, int WN, int FM, int FN>
+template <int WM, int WN, int FM, int FN, bool COLLECT>
 __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     constexpr int BM = WM * FM * 16;
     constexpr int BN = WN * FN * 16;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     f.per_wave = PER_WAVE;
     f.dbg_no_slow = (p.dbg & 16) != 0;
     f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
-    const bool collect = p.collect_thr != nullptr;      // second pass for uncertified queries
+    constexpr bool collect = COLLECT;                    // second pass for uncertified queries
     if (collect && *p.unc_count == 0) return;           // nothing failed its certificate
     f.collect_keys = collect ? p.collect_keys + (size_t)q0 * EXACT_CAP : nullptr;
     f.collect_cnt = collect ? p.collect_cnt + q0 : nullptr;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
                 __syncthreads();
                 publish_cmax(f, wave * PER_WAVE, PER_WAVE, lane);
             } else {
-                filter_tile<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
+                filter_tile<FM, FN, COLLECT>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
                 __syncthreads();   // appends of this tile visible workgroup-wide
                 if (__builtin_amdgcn_readfirstlane(f.flags[wave]) != 0) {
                     if (lane == 0) f.flags[wave] = 0;
@@ -246,12 +246,12 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool
         k.collect_thr = a.collect_thr; k.collect_keys = a.collect_keys; k.collect_cnt = a.collect_cnt;
         k.unc_count = a.unc_count;
     }
-    auto kern = scan_bf16_kernel<WM, WN, FM, FN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true> : scan_bf16_kernel<WM, WN, FM, FN, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[collect]) {
         SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
+        attr_set[collect] = true;
     }
     hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(THREADS), LDS, stream, k);
     SQE_HIP(hipGetLastError());

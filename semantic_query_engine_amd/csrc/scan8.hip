@@ -32,6 +32,8 @@
 // later (each storing wave drains its stores before the barrier in between).  Global-bound
 // rows are fetched by LDS-DMA in slot 0 (older than the six youngest DMA pieces at the slot-2
 // wait, hence retired by it) and folded at the next K step.
+#include <stdlib.h>
+
 #include "scan_common.h"
 
 namespace sqe {
@@ -112,6 +114,50 @@ __device__ __forceinline__ void mfma_quad_refill(f32x4 (&acc)[8][4], AFrag& a, c
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b[fn][kk], acc[I0 + fm][J0 + fn], 0, 0, 0);
             if (refill) a[fm][kk] = unit_frag(next_unit, ruA + fm * 16, kk * 4 + cq);
         }
+}
+
+// ---- two-slot form: 32 MFMAs per slot (one A set against both B sets)
+// Slot A: the A set (A^0) dies and is refilled with A^1 of the same K step.
+template <int I0>
+__device__ __forceinline__ void mfma_half_refill_a(f32x4 (&acc)[8][4], AFrag& a, const BFrag& b0, const BFrag& b1,
+                                                   const char* next_a, bool refill, int ruA, int cq) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn) {
+                acc[I0 + fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b0[fn][kk], acc[I0 + fm][fn], 0, 0, 0);
+                acc[I0 + fm][2 + fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b1[fn][kk], acc[I0 + fm][2 + fn], 0, 0, 0);
+            }
+            if (refill) a[fm][kk] = unit_frag(next_a, ruA + fm * 16, kk * 4 + cq);
+        }
+}
+// Slot B: everything dies -- A is refilled with A^0 of the next K step fragment by fragment, the two B
+// sets with B^0 / B^1 of the next K step after the half (kk) that last used them.
+template <int I0>
+__device__ __forceinline__ void mfma_half_refill_all(f32x4 (&acc)[8][4], AFrag& a, BFrag& b0, BFrag& b1,
+                                                     const char* next_a, const char* next_b0, const char* next_b1,
+                                                     bool refill, int ruA, int ruB, int cq) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn) {
+                acc[I0 + fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b0[fn][kk], acc[I0 + fm][fn], 0, 0, 0);
+                acc[I0 + fm][2 + fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm][kk], b1[fn][kk], acc[I0 + fm][2 + fn], 0, 0, 0);
+            }
+            if (refill) a[fm][kk] = unit_frag(next_a, ruA + fm * 16, kk * 4 + cq);
+        }
+        if (refill) {
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn) {
+                b0[fn][kk] = unit_frag(next_b0, ruB + fn * 16, kk * 4 + cq);
+                b1[fn][kk] = unit_frag(next_b1, ruB + fn * 16, kk * 4 + cq);
+            }
+        }
+    }
 }
 
 struct Pipe {
@@ -262,6 +308,86 @@ __device__ __forceinline__ void kstep(Pipe& P, const Filter& f, f32x4 (&acc)[8][
     P.advance();
 }
 
+// Two-slot K step (2 barriers instead of 4).  On entry a = A^0(s), bX = B^0(s), bY = B^1(s); on exit
+// the same for K step s+1.  Slot A: 32 MFMAs A^0 x {B^0, B^1}, a <- A^1(s); DMA of A^0, B^1, B^0 of
+// K step s+2 (their slots were last read in slot B of K step s-1); counted wait (the three units
+// just issued stay in flight, K step s+1 is retired).  Slot B: 32 MFMAs A^1 x {B^0, B^1} while
+// every fragment is replaced by K step s+1's; DMA of A^1(s+2).
+__device__ __forceinline__ void kstep2(Pipe& P, const Filter& f, f32x4 (&acc)[8][4], AFrag& a, BFrag& bX, BFrag& bY, int s) {
+    char* u0 = P.slot_of(s, 0);
+    char* u1 = P.slot_of(s, 1);
+    char* u2 = P.slot_of(s, 2);
+    char* u3 = P.slot_of(s, 3);
+    const bool more2 = s + 2 < P.S && !P.no_dma;
+    const bool more1 = s + 1 < P.S;
+    const bool entry_start = P.ks0 == 0 && s > 0 && !P.no_filter;
+
+    // ================= slot A
+    if (P.refresh_pending >= 0) {
+        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
+        P.refresh_pending = -1;
+    }
+    const bool want_refresh = P.e0 == 1 ? (P.ks0 >= P.KS / 4 && P.refresh_ctr < NSLICE8)
+                                        : (P.e0 <= 32 ? (P.ks0 % P.refresh_every) == 0 : P.ks0 == 0);
+    if (P.gshift >= 0 && P.e0 > 0 && want_refresh && !P.no_filter) {
+        P.refresh_pending = P.refresh_ctr % NSLICE8;
+        ++P.refresh_ctr;
+        refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
+    }
+    if (more2) {
+        issue_unit(P.a2, P.offA[0], P.offA[1], u0, P.wave);
+        issue_unit(P.b2 + P.b1_off, P.offB[0], P.offB[1], u1, P.wave);
+        issue_unit(P.b2, P.offB[0], P.offB[1], u3, P.wave);
+    }
+    if (P.ks0 == 0) {
+        if (s > 0 && !P.no_filter) {
+            const int64_t row0 = (int64_t)P.tile_of(P.e0 - 1) * SCAN_BM;
+            const int fl = fresh_lane();
+            if (P.e0 - 1 == 0) filter_boot<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl);
+            else filter_tile<8, 4>(acc, f, row0, P.wm * 128, P.wn * 64, fl);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!P.no_mma) mfma_half_refill_a<0>(acc, a, bX, bY, u2, true, P.ruA, P.cq);        // a <- A^1(s)
+    if (more2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    SQE_BARRIER();
+
+    // ================= slot B
+    if (entry_start) {
+        if (P.e0 - 1 == 0) {
+            publish_cmax(f, P.wave * 32, 32, fresh_lane());
+        } else {
+            const int fl = fresh_lane();
+            const int any_flag = __builtin_amdgcn_readfirstlane(__any(f.flags[fl & 7] != 0));
+            if (any_flag) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                SQE_BARRIER();
+                if (__builtin_amdgcn_readfirstlane(f.flags[P.wave]) != 0)
+                    compact_owned(f, P.wave * 32, 32, P.trig, P.kp, fl);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                SQE_BARRIER();
+                if (fl == 0) f.flags[P.wave] = 0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more2) issue_unit(P.a2 + P.a1_off, P.offA[0], P.offA[1], u2, P.wave);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!P.no_mma)
+        mfma_half_refill_all<4>(acc, a, bX, bY, P.slot_of(s + 1, 0), P.slot_of(s + 1, 3), P.slot_of(s + 1, 1), more1,
+                                P.ruA, P.ruB, P.cq);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SQE_BARRIER();
+
+    P.advance();
+}
+
+template <int SLOTS>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -376,13 +502,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     if (P.S > 0) {
         read_a(a, P.slot_of(0, 0), P.ruA, P.cq);
         read_b(bX, P.slot_of(0, 3), P.ruB, P.cq);
+        if constexpr (SLOTS == 2) read_b(bY, P.slot_of(0, 1), P.ruB, P.cq);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     SQE_BARRIER();                         // every wave holds its first fragments before slot 0 reuses u0
 
-    for (int s = 0; s < P.S; s += 2) {
-        kstep(P, f, acc, a, bX, bY, s);
-        if (s + 1 < P.S) kstep(P, f, acc, a, bY, bX, s + 1);
+    if constexpr (SLOTS == 2) {
+        for (int s = 0; s < P.S; ++s) kstep2(P, f, acc, a, bX, bY, s);
+    } else {
+        for (int s = 0; s < P.S; s += 2) {
+            kstep(P, f, acc, a, bX, bY, s);
+            if (s + 1 < P.S) kstep(P, f, acc, a, bY, bX, s + 1);
+        }
     }
 
     // ---- tail: filter of the last entry (the rescan of the first tile)
@@ -402,14 +533,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
 int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (plan.bn != BN8) return fail(SQE_ERR_INVALID, "scan p8: query block must be 256");
     ScanKernelArgs k = make_kernel_args(plan, a);
+    static const int slots = [] { const char* e = getenv("SQE_P8_SLOTS"); return e && e[0] == '4' ? 4 : 2; }();
+    auto kern = slots == 2 ? scan_bf16_p8_kernel<2> : scan_bf16_p8_kernel<4>;
     static bool attr_set = false;
     if (!attr_set) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bf16_p8_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(scan_bf16_p8_kernel, dim3(plan.n_chunks * plan.qblocks), dim3(SCAN_THREADS), LDS_BYTES,
-                       stream, k);
+    hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

@@ -204,7 +204,7 @@ __device__ __forceinline__ void publish_cmax(const Filter& f, int first_q, int p
 
 // Normal mode.  Returns true when this wave stored candidates (the caller drains its stores
 // before the next barrier so other waves can read the lists).
-template <int FM, int FN>
+template <int FM, int FN, bool COLLECT = false>
 __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Filter& f, int64_t tile_row0,
                                             int row0, int col0, int lane) {
     bool stored = false;
@@ -233,7 +233,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                             if (row < f.n_rows && qcol < f.q_live) {
                                 const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
                                 if (key > f.thr_key[qcol]) {
-                                    if (f.collect_keys) {
+                                    if constexpr (COLLECT) {
                                         const int gslot = atomicAdd(&f.collect_cnt[qcol], 1);
                                         if (gslot < EXACT_CAP) f.collect_keys[(size_t)qcol * EXACT_CAP + gslot] = key;
                                         continue;
