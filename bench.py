@@ -36,12 +36,53 @@ PEAK_HBM_GBPS = 8000.0
 
 def db_block(block: int, rows: int, device, seed: int = 1000) -> torch.Tensor:
     g = torch.Generator(device=device).manual_seed(seed + block)
-    return torch.randn((rows, D), generator=g, device=device, dtype=torch.float32)
+    x = torch.randn((rows, D), generator=g, device=device, dtype=torch.float32)
+    if os.environ.get("SQE_BENCH_DATA") == "zeros":     # clock experiments only (DVFS note)
+        x.zero_()
+    return x
 
 
 def make_queries(b: int, device, seed: int = 12345) -> torch.Tensor:
     g = torch.Generator(device=device).manual_seed(seed)
     return torch.randn((b, D), generator=g, device=device, dtype=torch.float32)
+
+
+def library_gemm_tflops(b: int, device) -> float:
+    """What the vendor GEMM (torch.matmul -> hipBLASLt) sustains on this box on the scan's own GEMM shape,
+    queries [b x 1024] x DB block [1M x 1024]^T, bf16 random operands, bf16 output, no top-k work: the
+    practical MFMA ceiling under this chip's power management, reported beside the nominal 2.5 PFLOP/s."""
+    n = 1 << 20
+    g = torch.Generator(device=device).manual_seed(7)
+    qm = torch.randn((b, D), generator=g, device=device).bfloat16()
+    dbm = torch.randn((n, D), generator=g, device=device).bfloat16()
+    out = torch.empty((b, n), dtype=torch.bfloat16, device=device)
+    for _ in range(5):
+        torch.matmul(qm, dbm.t(), out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        torch.matmul(qm, dbm.t(), out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del qm, dbm, out
+    torch.cuda.empty_cache()
+    return 2.0 * b * n * D / ms / 1e9
+
+
+def committed_traffic(rows: int, b: int) -> "float | None":
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (tools/pmc_scan.sh ->
+    profiles/r01_search/pmc_traffic.json), if they were taken on this workload; else None."""
+    path = os.path.join(ROOT, "profiles", "r01_search", "pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if t.get("rows") != rows or t.get("batch") != b:
+        return None
+    return float(t["hbm_bytes_per_launch"])
 
 
 def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
@@ -117,6 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--recall-queries", type=int, default=64)
+    ap.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +281,12 @@ def main():
         roof.update({"kernel": "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                      "hbm_gbps": round(gbps, 1), "mfma_tflops": round(tflops, 2)})
+        if world == 1:
+            roof["traffic"] = committed_traffic(n_total, b)
+        if roof["bound"] == "mfma" and world == 1 and not args.no_gemm_ref:
+            lib = library_gemm_tflops(b, device)
+            roof["library_gemm_tflops"] = round(lib, 1)
+            roof["frac_of_library_gemm"] = round(tflops / lib, 4)
         out = {
             "metric": "k-NN queries/sec (brute-force cosine top-10, 1024-d, 10M vectors)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,

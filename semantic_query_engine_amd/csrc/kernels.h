@@ -60,6 +60,9 @@ int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t str
 // pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless
 // unless the environment sets SQE_SCAN_P8=1 it uses the two-stage form (measured slightly faster).
 int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
+// ping-pong form for 256-query blocks (scan_pp.hip): the two waves of a SIMD alternate between a
+// compute phase and a memory phase.  Environment SQE_SCAN = pp | p8 | v0 picks the 256-query kernel.
+int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // second pass for uncertified queries: same scan, fixed thresholds args.collect_thr, every row at or
 // above its query's threshold goes to args.collect_keys; exits at once when *args.unc_count == 0
 int launch_scan_collect(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);

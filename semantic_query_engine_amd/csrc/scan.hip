@@ -306,12 +306,22 @@ int launch_scan_collect(const ScanPlan& plan, const ScanArgs& a, hipStream_t str
     return launch_cfg<8, 1, 2, 4>(plan, a, stream, true);
 }
 
+constexpr int SCAN_DEFAULT_KERNEL = 0;
+
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (a.K % SCAN_BK != 0) return fail(SQE_ERR_INVALID, "scan: dim must be a multiple of 64");
     if (plan.kp < 1 || plan.kp > MAX_KP) return fail(SQE_ERR_INVALID, "scan: kp out of range");
     if (plan.bn == 256) {
-        static const bool use_v0 = [] { const char* e = getenv("SQE_SCAN_P8"); return !(e && e[0] == '1'); }();
-        if (!use_v0) return launch_scan_bf16_p8(plan, a, stream);
+        // 0 = two-stage form below, 1 = scan8.hip, 2 = scan_pp.hip
+        static const int which = [] {
+            const char* e = getenv("SQE_SCAN");
+            if (e && e[0] == 'p' && e[1] == '8') return 1;
+            if (e && e[0] == 'v') return 0;
+            if (e && e[0] == 'p' && e[1] == 'p') return 2;
+            return SCAN_DEFAULT_KERNEL;
+        }();
+        if (which == 1) return launch_scan_bf16_p8(plan, a, stream);
+        if (which == 2) return launch_scan_bf16_pp(plan, a, stream);
         return launch_cfg<2, 4, 8, 4>(plan, a, stream);
     }
     return launch_cfg<8, 1, 2, 4>(plan, a, stream);

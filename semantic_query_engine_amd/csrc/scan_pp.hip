@@ -1,0 +1,445 @@
+// scan_pp.hip -- S2, ping-pong form of the bf16 scan for query blocks of 256 (gfx950).
+//
+// Same contract as scan.hip / scan8.hip (256-row DB tile x 256 queries per persistent workgroup,
+// fused top-k filter, candidate lists).  What differs is how the two waves that share a SIMD
+// are scheduled against each other:
+//
+//   Roles.  The 8 waves form two groups (waves w and w + 4 sit on the same SIMD): at any time one
+//     group is in a COMPUTE phase -- 32 back-to-back MFMAs on operands that are already in
+//     registers -- while the other is in a MEMORY phase: it issues its share of the LDS-DMA for a
+//     later K slice, reads its next operands from LDS (12 ds_read_b128) and runs whatever filter
+//     work is due.  One s_barrier closes every phase and the groups swap roles, so the matrix pipe
+//     of each SIMD always has one wave feeding it and nothing a wave waits for (LDS latency, DMA
+//     issue, filter VALU) sits between two of its own MFMAs.  Only ONE operand register set is
+//     needed (a wave never loads and computes at once): 128 accumulator + 48 operand VGPRs.
+//
+//   Half-steps.  The unit of the pipeline is a 32-wide K slice of the 256 x 256 tile: 256 rows x
+//     64 B of DB rows plus 256 x 64 B of queries = 32 KiB, one ring stage; 4 stages.  An LDS line
+//     (128 B) holds the slice of tile row L (chunks 0-3) and of row L + 128 (chunks 4-7), chunk
+//     positions XOR-swizzled by (L >> 1) & 7 -- the same conflict-free ds_read_b128 pattern the
+//     other scan kernels use, built by the per-lane source addresses of global_load_lds.
+//
+//   Timeline (phase p, half-step j; G0 = waves 0-3, G1 = waves 4-7):
+//         p = 2j     G0: MEM(j)      G1: CMP(j-1)
+//         p = 2j+1   G0: CMP(j)      G1: MEM(j)
+//     MEM(j) reads the operands of half-step j and issues the DMA of half-step j + 3 into the
+//     stage half-step j - 1 used, whose last readers (both groups' MEM(j-1)) retired their reads
+//     before an earlier barrier.  A counted wait at the end of MEM(j) retires this wave's DMA of
+//     half-step j + 1 (issued two of its MEM phases earlier) and leaves j + 2 and j + 3 in flight.
+//
+//   Filter.  The filter of a finished tile runs at the head of the wave's next MEM phase, under the
+//     partner's MFMAs; the first compute phase of a tile takes a zero C operand, so accumulators
+//     are never cleared by VALU moves.  Cross-wave steps (publishing boot maxima, list compaction)
+//     run two phases later, after both groups' filters and a barrier.
+#include <stdlib.h>
+
+#include "scan_common.h"
+
+namespace sqe {
+
+namespace {
+
+constexpr int HALF_K = 32;                         // k elements per half-step
+constexpr int LINE_BYTES = 128;                    // LDS line: the slices of tile rows L and L + 128
+constexpr int OPER_BYTES = 128 * LINE_BYTES;       // 16 KiB: one operand of one half-step
+constexpr int STAGE_BYTES = 2 * OPER_BYTES;        // DB rows, then queries
+constexpr int NSTAGE = 4;
+constexpr int BNP = 256;
+constexpr int OFF_F = NSTAGE * STAGE_BYTES;        // 128 KiB
+using FLP = FilterLds<BNP>;
+constexpr int LDS_BYTES = OFF_F + FLP::BYTES;
+constexpr int NSLICEP = BNP / GSLICE_Q;
+
+#define PP_BARRIER()                           \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef bf16x8 AOps[8];   // [fm]: 128 rows x 32 k
+typedef bf16x8 BOps[4];   // [fn]:  64 queries x 32 k
+
+struct Cursor {           // a half-step: (tile entry, 32-wide slice inside it)
+    int e, h;
+    const char* tile;     // first byte of the DB tile of entry e
+};
+
+struct PP {
+    const char* qbase;
+    char* smem;
+    char* gstage;
+    const uint32_t* gmax_group;
+    unsigned offA0, offA1, offB0, offB1;   // per-lane source offsets of this wave's DMA pieces
+    unsigned rdA, rdB;                     // per-lane LDS offsets of the operand reads inside a stage
+    int wave, wm, wn;
+    int tile_begin, nt, HS, J;
+    long long tile_bytes;
+    int kp, trig, gshift, refresh_every;
+    Cursor rd;                             // half-step the next MEM phase reads
+    Cursor dm;                             // half-step the next MEM phase fetches (rd + 3)
+    int refresh_pending, refresh_ctr, refresh_j;
+    int lean_until;                        // MEM phases of half-steps < lean_until take the lean form
+    int b_h, b_stage;                      // SPLIT: query pieces the next compute phase issues (b_h < 0: none)
+    bool no_mma, no_dma, no_filter;
+
+    __device__ __forceinline__ void advance(Cursor& c) const {
+        if (++c.h == HS) {
+            c.h = 0;
+            ++c.e;
+            c.tile += (c.e == nt) ? -(long long)(nt - 1) * tile_bytes : tile_bytes;   // entry nt = first tile again
+        }
+    }
+    __device__ __forceinline__ int64_t row0_of(int e) const {
+        return (int64_t)(e < nt ? tile_begin + e : tile_begin) * SCAN_BM;
+    }
+    // this wave's four 1-KiB pieces of a half-step: DB pieces wave, wave + 8; query pieces likewise
+    __device__ __forceinline__ void issue_a(const Cursor& c, int stage) const {
+        char* st = smem + stage * STAGE_BYTES;
+        const char* as = c.tile + c.h * (HALF_K * 2);
+        glds16(as + offA0, st + wave * 1024);
+        glds16(as + offA1, st + (wave + 8) * 1024);
+    }
+    __device__ __forceinline__ void issue_b(int h, int stage, int piece) const {
+        char* st = smem + stage * STAGE_BYTES + OPER_BYTES;
+        const char* bs = qbase + h * (HALF_K * 2);
+        if (piece == 0) glds16(bs + offB0, st + wave * 1024);
+        else glds16(bs + offB1, st + (wave + 8) * 1024);
+    }
+    __device__ __forceinline__ void issue(const Cursor& c, int stage) const {
+        issue_a(c, stage);
+        issue_b(c.h, stage, 0);
+        issue_b(c.h, stage, 1);
+    }
+};
+
+// FIRST: first half-step of a tile -- zero C operand, so accumulators are never cleared by VALU
+// moves.  The kernel's loops are nested (tile entries outside, half-steps inside, the first and
+// the last half-step peeled) so that the two variants never meet at a control-flow merge: with
+// `if (first) ... else ...` inside one flat loop hipcc keeps two accumulator sets and spills.
+template <bool FIRST, bool SPLIT>
+__device__ __forceinline__ void cmp_phase(const PP& P, f32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+        // SPLIT: the computing wave issues the two query pieces of half-step j + 3 between its MFMAs
+        // (the matrix pipe is the only thing it waits for), the loading wave only the DB pieces
+        if (SPLIT && (fm == 2 || fm == 5)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (P.b_h >= 0) P.issue_b(P.b_h, P.b_stage, fm == 2 ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                a[fm], b[fn], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn], 0, 0, 0);
+    }
+}
+
+// Phase 2j+2 of a tile boundary (j % HS == 0, j > 0): both groups' filters of the finished entry
+// are behind a barrier.  Every wave takes the same path (the flags are stable here).
+__device__ __forceinline__ void entry_sync(const PP& P, const Filter& f, int finished_entry) {
+    const int fl = fresh_lane();
+    if (finished_entry == 0) {
+        publish_cmax(f, P.wave * 32, 32, fl);
+    } else {
+        const int any_flag = __builtin_amdgcn_readfirstlane(__any(f.flags[fl & 7] != 0));
+        if (any_flag) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my appended keys are in memory
+            PP_BARRIER();
+            if (__builtin_amdgcn_readfirstlane(f.flags[P.wave]) != 0) compact_owned(f, P.wave * 32, 32, P.trig, P.kp, fl);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();                                                 // sweeps done before flags are cleared
+            if (fl == 0) f.flags[P.wave] = 0;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// MEMORY phase of half-step j (P.rd): filter work that is due, DMA of half-step j + 3, operand reads.
+// FILTER: this is the first half-step of an entry > 0, the accumulators hold the finished tile.
+template <bool FILTER, bool SPLIT>
+__device__ __forceinline__ void mem_phase(PP& P, const Filter& f, f32x4 (&acc)[8][4], AOps& a, BOps& b, int j) {
+    const bool more = j + 3 < P.J && !P.no_dma;
+
+    // ---- filter of the entry the previous compute phase finished
+    if (FILTER && !P.no_filter) {
+        const int fe = P.rd.e - 1;
+        const int fl = fresh_lane();
+        if (fe == 0) {
+            filter_boot<8, 4>(acc, f, P.row0_of(fe), P.wm * 128, P.wn * 64, fl);
+        } else {
+            // Appended keys are NOT drained: stores that sit between DMA pieces only make the counted
+            // waits below retire more than they must (vmcnt(N) leaves the N youngest operations of any
+            // kind in flight), never less.
+            filter_tile<8, 4>(acc, f, P.row0_of(fe), P.wm * 128, P.wn * 64, fl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- global bound: fold a slice fetched >= 3 half-steps ago (every wave's pieces have been
+    // retired by its counted waits and a barrier), then maybe fetch the next one
+    if (P.refresh_pending >= 0 && j >= P.refresh_j + 3) {
+        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
+        P.refresh_pending = -1;
+    }
+    // Schedule as in scan8.hip: entry 1 fetches all slices back to back from a quarter of the tile on
+    // (when every chunk has published its boot maxima), then every slice once per tile while the
+    // bound still moves fast, one slice per tile later.  At least 4 half-steps between fetches.
+    if (P.gshift >= 0 && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && j >= P.refresh_j + 4) {
+        const bool want = P.rd.e == 1 ? (P.rd.h >= P.HS / 4 && P.refresh_ctr < NSLICEP)
+                                      : (P.rd.e <= 32 ? (P.rd.h % P.refresh_every) == 0 : P.rd.h == 0);
+        if (want) {
+            P.refresh_pending = P.refresh_ctr % NSLICEP;
+            ++P.refresh_ctr;
+            P.refresh_j = j;
+            refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
+        }
+    }
+
+    // ---- DMA of half-step j + 3 into the stage of half-step j - 1
+    if (SPLIT) {
+        if (more) P.issue_a(P.dm, (j + 3) & 3);
+        P.b_h = more ? P.dm.h : -1;
+        P.b_stage = (j + 3) & 3;
+    } else {
+        if (more) P.issue(P.dm, (j + 3) & 3);
+    }
+
+    // ---- operands of half-step j
+    {
+        const char* st = P.smem + (j & 3) * STAGE_BYTES;
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + P.rdA + fm * 2048);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + P.rdB + fn * 2048);
+    }
+
+    // ---- retire the DMA of half-step j + 1 (two MEM phases old); j + 2 and j + 3 stay in flight.
+    // Anything else this wave issued in between (bound fetch, appended keys) only makes the wait
+    // retire part of j + 2 as well.
+    if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (SPLIT) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+
+    // ---- first half-step that needs this (general) form again; until then mem_lean runs
+    int next = j + 1;
+    if (P.refresh_pending < 0 && P.rd.e >= 2) {
+        if (P.gshift < 0 || P.no_filter || P.rd.e > 32) next = P.J;          // next fetch: a FILTER phase
+        else next = j + (P.refresh_every - (P.rd.h % P.refresh_every));
+    }
+    P.lean_until = P.no_dma ? 0 : min(next, P.J - 3);
+
+    P.advance(P.rd);
+    P.advance(P.dm);
+}
+
+// MEMORY phase without filter or bound work, j + 3 < J: the steady-state form.
+template <bool SPLIT>
+__device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j) {
+    if (SPLIT) {
+        P.issue_a(P.dm, (j + 3) & 3);
+        P.b_h = P.dm.h;
+        P.b_stage = (j + 3) & 3;
+    } else {
+        P.issue(P.dm, (j + 3) & 3);
+    }
+    const char* st = P.smem + (j & 3) * STAGE_BYTES;
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + P.rdA + fm * 2048);
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + P.rdB + fn * 2048);
+    if (SPLIT) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    P.advance(P.rd);
+    P.advance(P.dm);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    PP P;
+    P.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = P.wave >> 2;           // waves w and w + 4 share a SIMD
+    P.wm = P.wave >> 2;
+    P.wn = P.wave & 3;
+    P.smem = smem;
+    P.gstage = smem + OFF_F + FLP::OFF_GSTAGE;
+
+    int logical = blockIdx.x;
+    const int G = gridDim.x;
+    if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
+    const int q0 = qb * BNP;
+
+    P.tile_begin = chunk * p.tiles_per_chunk;
+    const int tile_end = min(p.n_tiles, P.tile_begin + p.tiles_per_chunk);
+    P.nt = tile_end - P.tile_begin;
+    P.HS = p.K / HALF_K;
+    // entries: 0 = first tile (BOOT), 1..nt-1 = the other tiles, nt = the first tile again
+    const int n_entries = P.nt > 0 ? P.nt + 1 : 0;
+    P.J = n_entries * P.HS;
+    const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
+    P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
+    P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift;
+    P.refresh_every = P.HS >= NSLICEP ? P.HS / NSLICEP : 1;
+    P.no_mma = (p.dbg & 1) != 0; P.no_dma = (p.dbg & 2) != 0; P.no_filter = (p.dbg & 4) != 0;
+    if (p.dbg & 8) P.gshift = -1;
+
+    Filter f;
+    f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    f.gstride = p.ngroups * GMAX_COLS * 64;
+    P.gmax_group = p.gmax + ((size_t)(q0 / 64) * p.ngroups + (chunk % p.ngroups)) * (GMAX_COLS * 64);
+    f.gmax_mine = const_cast<uint32_t*>(P.gmax_group) + (chunk / p.ngroups) * 64;
+    f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FLP::OFF_THR_KEY);
+    f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FLP::OFF_THR_S);
+    f.cnt = reinterpret_cast<int*>(smem + OFF_F + FLP::OFF_CNT);
+    f.cmax = reinterpret_cast<uint32_t*>(smem + OFF_F + FLP::OFF_CMAX);
+    f.flags = reinterpret_cast<int*>(smem + OFF_F + FLP::OFF_FLAGS);
+    f.n_rows = p.n_rows;
+    f.q_live = min(BNP, p.B - q0);
+    f.trig = p.trig;
+    f.per_wave = 32;
+    f.dbg_no_slow = (p.dbg & 16) != 0;
+    f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
+    f.collect_keys = nullptr; f.collect_cnt = nullptr;
+    for (int i = tid; i < BNP; i += SCAN_THREADS) {
+        const bool live = (q0 + i) < p.B;
+        f.thr_key[i] = live ? 0ull : ~0ull;
+        f.thr_s[i] = live ? -INFINITY : INFINITY;
+        f.cnt[i] = 0;
+        f.cmax[i] = 0u;
+    }
+    if (tid < 16) f.flags[tid] = 0;
+
+    // ---- per-lane DMA source offsets.  Piece t covers LDS lines 8t .. 8t+7; lane l writes chunk
+    // position l & 7 of line 8t + (l >> 3), which holds logical chunk c = pos ^ ((line >> 1) & 7):
+    // bytes (c & 3) * 16 of the slice of tile row line + 128 * (c >> 2).
+    {
+        const int line = P.wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((line >> 1) & 7);
+        const int row = line + 128 * (c >> 2);
+        P.offA0 = (unsigned)(row * ldA) + (c & 3) * 16;
+        P.offB0 = (unsigned)(row * ldB) + (c & 3) * 16;
+        P.offA1 = P.offA0 + (unsigned)(64 * ldA);      // piece wave + 8: 64 lines further, same swizzle
+        P.offB1 = P.offB0 + (unsigned)(64 * ldB);
+    }
+    // ---- per-lane operand read offsets: fragment fm / fn adds fm * 2048 (16 lines)
+    {
+        const int r = lane & 15, cq = lane >> 4, sw = (r >> 1) & 7;
+        P.rdA = (unsigned)(r * LINE_BYTES + (((P.wm * 4 + cq) ^ sw) << 4));
+        P.rdB = (unsigned)(((P.wn & 1) * 64 + r) * LINE_BYTES + ((((P.wn >> 1) * 4 + cq) ^ sw) << 4));
+    }
+    P.qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ldB;
+    const char* tile0 = reinterpret_cast<const char*>(p.db) + (size_t)P.tile_begin * SCAN_BM * ldA;
+    P.rd = Cursor{0, 0, tile0};
+    P.dm = Cursor{0, 0, tile0};
+    P.refresh_pending = -1;
+    P.refresh_ctr = 0;
+    P.refresh_j = -100;
+    P.b_h = -1; P.b_stage = 0;
+    P.lean_until = 0;
+
+    f32x4 acc[8][4];
+    AOps a;
+    BOps b;
+
+    // ---- prologue: half-steps 0, 1, 2 (J >= 4 whenever J > 0: boot + rescan entries, K >= 64)
+    if (P.J > 0) {
+        for (int s = 0; s < 3; ++s) {
+            P.issue(P.dm, s);
+            P.advance(P.dm);
+        }
+    }
+    __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
+
+    if (P.J > 0) {
+        const int HS = P.HS;
+        int j = 0;                         // half-step of the compute phase
+        if (group == 0) {
+            mem_phase<false, SPLIT>(P, f, acc, a, b, 0);
+            PP_BARRIER();
+            for (int e = 0; e < n_entries; ++e) {
+                // h = 0
+                if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
+                PP_BARRIER();
+                if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
+                mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                PP_BARRIER();
+                ++j;
+                for (int h = 1; h < HS - 1; ++h) {
+                    if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                    PP_BARRIER();
+                    if (j + 1 < P.lean_until) mem_lean<SPLIT>(P, a, b, j + 1);
+                    else mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                    PP_BARRIER();
+                    ++j;
+                }
+                // h = HS - 1: the next MEM phase opens entry e + 1 and filters entry e
+                if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                PP_BARRIER();
+                if (e + 1 < n_entries) mem_phase<true, SPLIT>(P, f, acc, a, b, j + 1);
+                PP_BARRIER();
+                ++j;
+            }
+        } else {
+            PP_BARRIER();
+            for (int e = 0; e < n_entries; ++e) {
+                // h = 0
+                if (e > 0) mem_phase<true, SPLIT>(P, f, acc, a, b, j);
+                else mem_phase<false, SPLIT>(P, f, acc, a, b, j);
+                PP_BARRIER();
+                if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
+                if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
+                PP_BARRIER();
+                ++j;
+                for (int h = 1; h < HS; ++h) {
+                    if (j < P.lean_until) mem_lean<SPLIT>(P, a, b, j);
+                    else mem_phase<false, SPLIT>(P, f, acc, a, b, j);
+                    PP_BARRIER();
+                    if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                    PP_BARRIER();
+                    ++j;
+                }
+            }
+        }
+    }
+
+    // ---- tail: filter of the last entry (the rescan of the first tile)
+    if (P.J > 0 && !P.no_filter) {
+        if (filter_tile<8, 4>(acc, f, (int64_t)P.tile_begin * SCAN_BM, P.wm * 128, P.wn * 64, lane))
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    compact_owned(f, P.wave * 32, 32, p.kp + 1, p.kp, lane);
+    __syncthreads();
+    for (int i = tid; i < BNP; i += SCAN_THREADS)
+        p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
+}
+
+}  // namespace
+
+int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
+    if (plan.bn != BNP) return fail(SQE_ERR_INVALID, "scan pp: query block must be 256");
+    ScanKernelArgs k = make_kernel_args(plan, a);
+    static const bool split = [] { const char* e = getenv("SQE_PP_SPLIT"); return !(e && e[0] == '0'); }();
+    auto kern = split ? scan_bf16_pp_kernel<true> : scan_bf16_pp_kernel<false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+}  // namespace sqe
