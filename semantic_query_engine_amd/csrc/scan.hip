@@ -36,6 +36,15 @@ constexpr int ROW_BYTES = SCAN_ROW_BYTES;
 
 // Issue the global->LDS copy of ROWS tile rows x 64 k (128 B per row) spread over the 8
 // waves.  `gbase` points at (tile_row0, k0); `ld_bytes` is the global row pitch.
+// barrier that orders LDS traffic only (no vmcnt drain: DMA stays in flight)
+#define LDS_BARRIER()                                          \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        __builtin_amdgcn_s_barrier();                          \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
 template <int ROWS>
 __device__ __forceinline__ void stage_tile(const char* gbase, size_t ld_bytes, char* lds, int wave, int lane) {
     constexpr int NINSTR = ROWS / 8;          // one 1-KiB wave-instruction per 8 rows
@@ -49,9 +58,7 @@ __device__ __forceinline__ void stage_tile(const char* gbase, size_t ld_bytes, c
             const int r = g * 8 + r_local;
             const int c = cprime ^ ((r >> 1) & 7);
             const char* src = gbase + (size_t)r * ld_bytes + c * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + g * 1024),
-                                             16, 0, 0);
+            lds_dma16(src, lds + g * 1024);
         }
     }
 }
@@ -60,7 +67,10 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(tile + r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
-template <int WM, int WN, int FM, int FN, bool COLLECT>
+// NST = LDS ring depth: NST - 1 K steps of DMA are in flight while one is computed.  2 for the
+// 256-query block (MFMA-bound); 3 for the 64-query block, which is HBM-bound and needs the extra
+// 40 KiB per CU in flight to cover the memory latency.
+template <int WM, int WN, int FM, int FN, bool COLLECT, int NST>
 __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     constexpr int BM = WM * FM * 16;
     constexpr int BN = WN * FN * 16;
@@ -68,7 +78,9 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     static_assert(WM * WN == NWAVES, "8 waves");
     static_assert(BN % GSLICE_Q == 0, "query block is a whole number of refresh slices");
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int OFF_F = 2 * STAGE_BYTES;
+    constexpr int OFF_F = NST * STAGE_BYTES;
+    constexpr int PIECES = (BM / 8 + BN / 8) / NWAVES;   // DMA wave-instructions per wave per stage
+    static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "every wave issues the same number of pieces");
     using FL = FilterLds<BN>;
     constexpr int PER_WAVE = BN / NWAVES;
     constexpr int NSLICE = BN / GSLICE_Q;
@@ -150,32 +162,32 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 
     f32x4 acc[FM][FN];
 
-    if (total_stages > 0) {
-        stage_tile<BM>(dbbase + (size_t)tile_begin * BM * ldA + (size_t)kslice(0) * ROW_BYTES, ldA, smem, wave, lane);
-        stage_tile<BN>(qbase + (size_t)kslice(0) * ROW_BYTES, ldB, smem + BM * ROW_BYTES, wave, lane);
-    }
-    __syncthreads();   // vmcnt(0) + barrier: stage 0 landed, state initialised
+    // stage index -> (entry, K step) of the stage the DMA cursor points at
+    int d_entry = 0, d_ks = 0;
+    auto issue_stage = [&](int s_idx) {
+        char* buf = smem + (s_idx % NST) * STAGE_BYTES;
+        stage_tile<BM>(dbbase + (size_t)tile_of(d_entry) * BM * ldA + (size_t)kslice(d_ks) * ROW_BYTES, ldA, buf, wave, lane);
+        stage_tile<BN>(qbase + (size_t)kslice(d_ks) * ROW_BYTES, ldB, buf + BM * ROW_BYTES, wave, lane);
+        if (++d_ks == KS) { d_ks = 0; ++d_entry; }
+    };
+    for (int s = 0; s < NST - 1 && s < total_stages; ++s) issue_stage(s);
+    __syncthreads();   // vmcnt(0) + barrier: prologue stages landed, state initialised
 
     int entry = 0;
     int ks = 0;
     int refresh_pending = -1;      // slice fetched during the previous K step
     int refresh_ctr = 0;
     for (int s = 0; s < total_stages; ++s) {
-        char* cur = smem + (s & 1) * STAGE_BYTES;
+        char* cur = smem + (s % NST) * STAGE_BYTES;
         // the bound rows fetched during the previous K step have landed (barrier below)
         if (refresh_pending >= 0) {
             if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, lane);
             refresh_pending = -1;
         }
-        // prefetch the next stage into the other buffer (its readers finished before the
-        // barrier that ended the previous iteration)
-        if (s + 1 < total_stages) {
-            int nentry = entry, nks = ks + 1;
-            if (nks == KS) { nks = 0; ++nentry; }
-            char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
-            stage_tile<BM>(dbbase + (size_t)tile_of(nentry) * BM * ldA + (size_t)kslice(nks) * ROW_BYTES, ldA, nxt, wave, lane);
-            stage_tile<BN>(qbase + (size_t)kslice(nks) * ROW_BYTES, ldB, nxt + BM * ROW_BYTES, wave, lane);
-        }
+        // prefetch stage s + NST - 1 into the buffer stage s - 1 used (its readers finished before
+        // the barrier that ended the previous iteration)
+        const bool more = s + NST - 1 < total_stages;
+        if (more) issue_stage(s + NST - 1);
         {
             // Bound refresh schedule: entry 1 fetches every slice back to back from K step KS/4 on
             // (after every chunk has published its boot maxima); later one slice per tile.
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             if (want && p.gshift >= 0 && !collect) {
                 refresh_pending = refresh_ctr % NSLICE;
                 ++refresh_ctr;
-                refresh_issue(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
+                refresh_issue<true>(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
             }
         }
         if (ks == 0) {
@@ -213,20 +225,40 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             const int64_t row0 = (int64_t)tile_of(entry) * BM;
             if (entry == 0 && !collect) {
                 filter_boot<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
-                __syncthreads();
+                LDS_BARRIER();
                 publish_cmax(f, wave * PER_WAVE, PER_WAVE, lane);
+                wait_vm0_visible();
             } else {
-                filter_tile<FM, FN, COLLECT>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
-                __syncthreads();   // appends of this tile visible workgroup-wide
-                if (__builtin_amdgcn_readfirstlane(f.flags[wave]) != 0) {
+                // The DMA pieces are invisible to hipcc (lds_dma16), so any wait it inserts for a pending
+                // store of its own is a vmcnt(0) that drains the ring.  Waves that stored keys retire
+                // them here, inside the rare branch, and the compiler's state is clean on every path
+                // back to the K loop.
+                if (filter_tile<FM, FN, COLLECT>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane)) wait_vm0_visible();
+                LDS_BARRIER();       // every wave's flags are set
+                // Appended keys only have to be in memory when a list is compacted; every wave reads
+                // the same flag words, so the branch and its barriers are uniform.
+                if (__builtin_amdgcn_readfirstlane(__any(f.flags[lane & 7] != 0))) {
+                    __syncthreads();                                  // vmcnt(0): keys visible workgroup-wide
+                    if (__builtin_amdgcn_readfirstlane(f.flags[wave]) != 0) {
+                        compact_owned(f, wave * PER_WAVE, PER_WAVE, p.trig, p.kp, lane);
+                        wait_vm0_visible();
+                    }
+                    LDS_BARRIER();                                    // flags read before they are cleared
                     if (lane == 0) f.flags[wave] = 0;
-                    compact_owned(f, wave * PER_WAVE, PER_WAVE, p.trig, p.kp, lane);
                 }
             }
         }
         ++ks;
         if (ks == KS) { ks = 0; ++entry; }
-        __syncthreads();   // next stage landed (vmcnt(0)); everyone done with `cur`; state settled
+        // stage s + 1 landed (the NST - 2 younger stages stay in flight; anything else this wave issued
+        // in between only makes the wait retire more); everyone done with `cur`; filter state settled
+        if (NST == 2 || !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (PIECES * (NST - 2) == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if (PIECES * (NST - 2) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     if (collect) return;                                 // keys went straight to the per-query buffers
@@ -237,16 +269,17 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
 }
 
-template <int WM, int WN, int FM, int FN>
+template <int WM, int WN, int FM, int FN, int NST>
 int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool collect = false) {
     constexpr int BN = WN * FN * 16;
-    constexpr int LDS = 2 * (SCAN_BM + BN) * ROW_BYTES + FilterLds<BN>::BYTES;
+    constexpr int LDS = NST * (SCAN_BM + BN) * ROW_BYTES + FilterLds<BN>::BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     ScanKernelArgs k = make_kernel_args(plan, a);
     if (collect) {
         k.collect_thr = a.collect_thr; k.collect_keys = a.collect_keys; k.collect_cnt = a.collect_cnt;
         k.unc_count = a.unc_count;
     }
-    auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true> : scan_bf16_kernel<WM, WN, FM, FN, false>;
+    auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true, NST> : scan_bf16_kernel<WM, WN, FM, FN, false, NST>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[collect]) {
         SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -302,8 +335,8 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
 int launch_scan_collect(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (!a.collect_thr || !a.collect_keys || !a.collect_cnt || !a.unc_count)
         return fail(SQE_ERR_INVALID, "scan collect: missing buffers");
-    if (plan.bn == 256) return launch_cfg<2, 4, 8, 4>(plan, a, stream, true);
-    return launch_cfg<8, 1, 2, 4>(plan, a, stream, true);
+    if (plan.bn == 256) return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream, true);
+    return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream, true);
 }
 
 constexpr int SCAN_DEFAULT_KERNEL = 0;
@@ -322,9 +355,9 @@ int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream
         }();
         if (which == 1) return launch_scan_bf16_p8(plan, a, stream);
         if (which == 2) return launch_scan_bf16_pp(plan, a, stream);
-        return launch_cfg<2, 4, 8, 4>(plan, a, stream);
+        return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream);
     }
-    return launch_cfg<8, 1, 2, 4>(plan, a, stream);
+    return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream);
 }
 
 }  // namespace sqe

@@ -75,6 +75,23 @@ struct FilterLds {
     static constexpr int BYTES = OFF_GSTAGE + GSTAGE_BYTES;
 };
 
+// Filter event counters (appends, slow-path entries, compactions) are compiled in only with
+// -DSQE_FILTER_COUNTERS (make COUNTERS=1) and then switched on by SQE_DBG bit 32: a global atomic in
+// the filter, even behind a run-time flag, is one more pending VMEM event hipcc has to guard against.
+#ifdef SQE_FILTER_COUNTERS
+#define SQE_COUNT(f, idx, cond)                                                    \
+    do {                                                                           \
+        if ((f).dbg_counters && (cond)) atomicAdd(&(f).dbg_counters[idx], 1ull);   \
+    } while (0)
+#else
+#define SQE_COUNT(f, idx, cond) \
+    do {                        \
+    } while (0)
+#endif
+
+// s_waitcnt vmcnt(0) the compiler can see (expcnt / lgkmcnt fields left at their maxima)
+__device__ __forceinline__ void wait_vm0_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 struct Filter {
     uint64_t* cand_base;   // this workgroup's lists: [BN][CAND_CAP]
     uint32_t* gmax_mine;   // this chunk's column of slice 0 of the block: query q at [(q/64)*gstride + q%64]
@@ -96,6 +113,19 @@ struct Filter {
 
 // host: kernel argument block from a plan (scan.hip)
 ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a);
+
+// global -> LDS copy of 16 B per lane (LDS destination = wave-uniform base + lane * 16) as inline asm.
+// Through the builtin, hipcc tracks every LDS-DMA piece as a pending write to LDS and puts
+// s_waitcnt vmcnt(0) in front of the next LDS read it sees, which drains the ring; kernels that keep
+// stages in flight across LDS reads issue their pieces here and count their own waits.
+__device__ __forceinline__ void lds_dma16(const char* src, char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_sc1(const char* src, char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(src), "s"(dst) : "memory");
+}
 
 __device__ __forceinline__ void store_sc1_u32(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -161,7 +191,7 @@ __device__ __forceinline__ void compact_owned(const Filter& f, int first_q, int 
     while (mask) {
         const int bq = first_q + (int)__builtin_ctzll(mask);
         mask &= mask - 1;
-        if (f.dbg_counters && lane == 0) atomicAdd(&f.dbg_counters[2], 1ull);
+        SQE_COUNT(f, 2, lane == 0);
         compact_list(f.cand_base + (size_t)bq * CAND_CAP, f.cnt[bq], kp, lane, &f.cnt[bq], &f.thr_s[bq],
                      &f.thr_key[bq]);
     }
@@ -221,7 +251,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
             mx = fmaxf(mx, fmx[i]);
         }
         if (__any(mx >= thr) && !f.dbg_no_slow) {    // rare: some lane of this column group has a survivor
-            if (f.dbg_counters && lane == 0) atomicAdd(&f.dbg_counters[1], 1ull);
+            SQE_COUNT(f, 1, lane == 0);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (__any(fmx[i] >= thr)) {
@@ -239,7 +269,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                                         continue;
                                     }
                                     const int slot = atomicAdd(&f.cnt[qcol], 1);
-                                    if (f.dbg_counters) atomicAdd(&f.dbg_counters[0], 1ull);
+                                    SQE_COUNT(f, 0, true);
                                     f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;
                                     if (slot + 1 >= f.trig) f.flags[qcol / f.per_wave] = 1;
                                     const uint32_t o = (uint32_t)(key >> 32);
@@ -260,12 +290,17 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
 // ---------------------------------------------------------------- global bound refresh
 // Issue the LDS-DMA fetch of one query slice of the table (64 columns x 64 queries x 4 B =
 // 16 KiB, contiguous): 16 pieces of 1 KiB, wave w issues pieces w and w + 8.
+template <bool ASM_DMA = false>
 __device__ __forceinline__ void refresh_issue(const uint32_t* gmax_block_group, int gstride, int sl,
                                               char* gstage, int wave, int lane) {
     const char* src = reinterpret_cast<const char*>(gmax_block_group + (size_t)sl * gstride) + lane * 16;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int piece = wave + 8 * t;
+        if constexpr (ASM_DMA) {
+            lds_dma16_sc1(src + piece * 1024, gstage + piece * 1024);
+            continue;
+        }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
                                          (__attribute__((address_space(3))) void*)(gstage + piece * 1024),
                                          16, 0, /*aux: sc1*/ 16);
