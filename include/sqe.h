@@ -41,7 +41,8 @@ enum {
     SQE_ERR_HIP = -2,         /* a HIP runtime call failed */
     SQE_ERR_OOM = -3,         /* device or host allocation failed */
     SQE_ERR_STATE = -4,       /* object not in a state that allows the call */
-    SQE_ERR_UNSUPPORTED = -5  /* valid request this build does not implement */
+    SQE_ERR_UNSUPPORTED = -5, /* valid request this build does not implement */
+    SQE_ERR_IO = -6           /* file could not be opened, read or written, or is not a saved index */
 };
 
 enum { SQE_INDEX_FLAT = 0, SQE_INDEX_IVF_FLAT = 1 };
@@ -112,6 +113,14 @@ int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int it
 /* IVF introspection: normalised centroids [nlist, dim] and the list of every stored row [count]
  * (either pointer may be NULL). */
 int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host);
+
+/* Persistence.  The reference keeps its vectors in the OpenSearch index across restarts and skips the
+ * rebuild when `has_any_data()` is true (main.py:300-307, :422-424); here the index lives in HBM, so it
+ * is written to / read from a local file: the normalised fp32 rows (plus IVF centroids and list
+ * assignments) exactly as stored -- a loaded index returns bit-identical results.  The scanned bf16
+ * copy and the IVF lists are rebuilt on load.  `sqe_index_load` creates the index. */
+int sqe_index_save(sqe_index* idx, const char* path);
+int sqe_index_load(sqe_ctx* ctx, const char* path, sqe_index** out);
 
 /* Merge of per-shard results after the all-gather of a row-sharded index: part p holds
  * cos [B,k] fp32 at cos_parts_dev + p * part_stride_bytes and global ids [B,k] int64

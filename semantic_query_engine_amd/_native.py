@@ -54,6 +54,8 @@ SIGNATURES = {
     "sqe_index_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64]),
     "sqe_index_train_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64]),
     "sqe_index_ivf_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqe_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "sqe_index_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "sqe_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sqe_cosine_best": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_float_p, c_i32_p]),
     "sqe_cosine_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

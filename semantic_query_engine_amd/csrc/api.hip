@@ -218,6 +218,8 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
 int ivf_export(sqe_index* base, IvfState* st, float* centroids_host, int32_t* assign_host);
 void ivf_invalidate(IvfState* st);
 sqe_index* ivf_coarse(IvfState* st);
+bool ivf_trained(IvfState* st);
+int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const int32_t* assign_dev, int64_t n);
 }  // namespace sqe
 
 // accessors used by encoder.hip / ivf.hip (sqe_ctx and sqe_index are defined in this file only)
@@ -229,6 +231,20 @@ int index_nlist(sqe_index* idx) { return idx->nlist; }
 int64_t index_id_base(sqe_index* idx) { return idx->id_base; }
 sqe_ctx* index_ctx(sqe_index* idx) { return idx->ctx; }
 void index_clear(sqe_index* idx) { idx->n = 0; }
+// append rows that are already normalised (saved index): master bit for bit, bf16 copy + residual rebuilt
+int index_add_restored(sqe_index* idx, const float* x_dev, int64_t n) {
+    if (n <= 0) return SQE_OK;
+    SQE_TRY(index_grow(idx, idx->n + n));
+    if (!idx->resid_max.p) {
+        SQE_TRY(idx->resid_max.ensure(16));
+        SQE_HIP(hipMemsetAsync(idx->resid_max.p, 0, 16, idx->ctx->stream));
+    }
+    SQE_TRY(launch_restore_rows(x_dev, n, idx->dim, idx->master + (size_t)idx->n * idx->dim,
+                                idx->scan + (size_t)idx->n * (idx->pitch / 2), idx->pitch / 2,
+                                idx->resid_max.as<uint32_t>(), idx->ctx->stream));
+    idx->n += n;
+    return SQE_OK;
+}
 hipStream_t ctx_stream(sqe_ctx* ctx) { return ctx->stream; }
 int ctx_cu_count(sqe_ctx* ctx) { return ctx->cu_count; }
 int ctx_device(sqe_ctx* ctx) { return ctx->device; }
@@ -619,6 +635,122 @@ int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_
     SQE_ENTER(idx->ctx);
     if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_ivf_export: not an IVF index");
     return ivf_export(idx, idx->ivf, centroids_host, assign_host);
+}
+
+// ---------------------------------------------------------------- persistence
+// File: 64-byte header | master rows [n, dim] fp32 | (IVF, trained) centroids [nlist, dim] fp32 | assign [n] int32.
+// The bf16 scan copy, residuals and IVF lists are derived data and are rebuilt on load.
+namespace {
+struct SaveHeader {
+    char magic[8];          // "SQEIDX01"
+    uint32_t version, dim, kind, nlist;
+    int64_t n, id_base;
+    uint32_t flags;         // bit 0: IVF centroids + assignments follow
+    uint32_t certify;
+    uint8_t pad[16];
+};
+static_assert(sizeof(SaveHeader) == 64, "header layout");
+constexpr size_t IO_CHUNK = 64u << 20;
+
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(SQE_ERR_OOM, std::string("pinned staging: ") + hipGetErrorString(e));
+        return SQE_OK;
+    }
+};
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() { if (f) fclose(f); }
+};
+
+int write_device_range(FILE* f, const void* dev, size_t bytes, void* pinned, hipStream_t s) {
+    for (size_t off = 0; off < bytes; off += IO_CHUNK) {
+        const size_t m = std::min(IO_CHUNK, bytes - off);
+        SQE_HIP(hipMemcpyAsync(pinned, (const char*)dev + off, m, hipMemcpyDeviceToHost, s));
+        SQE_HIP(hipStreamSynchronize(s));
+        if (fwrite(pinned, 1, m, f) != m) return fail(SQE_ERR_IO, "sqe_index_save: short write");
+    }
+    return SQE_OK;
+}
+}  // namespace
+
+int sqe_index_save(sqe_index* idx, const char* path) {
+    if (!idx || !path) return fail(SQE_ERR_INVALID, "sqe_index_save: null argument");
+    SQE_ENTER(idx->ctx);
+    sqe_ctx* c = idx->ctx;
+    const bool ivf = idx->ivf && ivf_trained(idx->ivf);
+    if (ivf) SQE_TRY(ivf_rows_added(idx, idx->ivf));
+    FileCloser fc{fopen(path, "wb")};
+    if (!fc.f) return fail(SQE_ERR_IO, std::string("sqe_index_save: cannot open ") + path);
+    SaveHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "SQEIDX01", 8);
+    h.version = 1; h.dim = (uint32_t)idx->dim; h.kind = (uint32_t)idx->kind; h.nlist = (uint32_t)idx->nlist;
+    h.n = idx->n; h.id_base = idx->id_base; h.flags = ivf ? 1u : 0u; h.certify = (uint32_t)idx->certify;
+    if (fwrite(&h, 1, sizeof(h), fc.f) != sizeof(h)) return fail(SQE_ERR_IO, "sqe_index_save: short write");
+    PinnedBuf pin;
+    SQE_TRY(pin.alloc(IO_CHUNK));
+    SQE_HIP(hipStreamSynchronize(c->stream));
+    SQE_TRY(write_device_range(fc.f, idx->master, (size_t)idx->n * idx->dim * 4, pin.p, c->stream));
+    if (ivf) {
+        std::vector<float> cent((size_t)idx->nlist * idx->dim);
+        std::vector<int32_t> assign((size_t)std::max<int64_t>(idx->n, 1));
+        SQE_TRY(ivf_export(idx, idx->ivf, cent.data(), assign.data()));
+        if (fwrite(cent.data(), 4, cent.size(), fc.f) != cent.size()) return fail(SQE_ERR_IO, "sqe_index_save: short write");
+        if (idx->n > 0 && fwrite(assign.data(), 4, (size_t)idx->n, fc.f) != (size_t)idx->n)
+            return fail(SQE_ERR_IO, "sqe_index_save: short write");
+    }
+    if (fflush(fc.f) != 0) return fail(SQE_ERR_IO, "sqe_index_save: flush failed");
+    return SQE_OK;
+}
+
+int sqe_index_load(sqe_ctx* ctx, const char* path, sqe_index** out) {
+    if (!ctx || !path || !out) return fail(SQE_ERR_INVALID, "sqe_index_load: null argument");
+    SQE_ENTER(ctx);
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f) return fail(SQE_ERR_IO, std::string("sqe_index_load: cannot open ") + path);
+    SaveHeader h;
+    if (fread(&h, 1, sizeof(h), fc.f) != sizeof(h) || memcmp(h.magic, "SQEIDX01", 8) != 0 || h.version != 1)
+        return fail(SQE_ERR_IO, "sqe_index_load: not a saved index (bad header)");
+    if (h.n < 0 || h.dim == 0 || h.dim % 64 != 0) return fail(SQE_ERR_IO, "sqe_index_load: corrupt header");
+    sqe_index* idx = nullptr;
+    SQE_TRY(sqe_index_create(ctx, (int)h.dim, (int)h.kind, (int)h.nlist, &idx));
+    struct Guard {
+        sqe_index* i;
+        ~Guard() { if (i) sqe_index_destroy(i); }
+    } guard{idx};
+    idx->id_base = h.id_base;
+    idx->certify = (int)h.certify;
+    SQE_TRY(index_grow(idx, h.n));
+    PinnedBuf pin;
+    SQE_TRY(pin.alloc(IO_CHUNK));
+    const size_t row_bytes = (size_t)h.dim * 4;
+    const int64_t rows_per_step = std::max<int64_t>(1, (int64_t)(IO_CHUNK / row_bytes));
+    SQE_TRY(ctx->stage_in.ensure((size_t)std::min<int64_t>(rows_per_step, std::max<int64_t>(h.n, 1)) * row_bytes));
+    for (int64_t off = 0; off < h.n; off += rows_per_step) {
+        const int64_t m = std::min(rows_per_step, h.n - off);
+        if (fread(pin.p, row_bytes, (size_t)m, fc.f) != (size_t)m) return fail(SQE_ERR_IO, "sqe_index_load: file is truncated");
+        SQE_HIP(hipMemcpyAsync(ctx->stage_in.p, pin.p, (size_t)m * row_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SQE_TRY(index_add_restored(idx, ctx->stage_in.as<float>(), m));
+        SQE_HIP(hipStreamSynchronize(ctx->stream));    // the pinned buffer is reused
+    }
+    if (h.flags & 1u) {
+        if (!idx->ivf) return fail(SQE_ERR_IO, "sqe_index_load: IVF section in a flat index file");
+        const size_t cb = (size_t)h.nlist * row_bytes, ab = (size_t)h.n * 4;
+        std::vector<char> host(cb + ab);
+        if (fread(host.data(), 1, cb + ab, fc.f) != cb + ab) return fail(SQE_ERR_IO, "sqe_index_load: file is truncated");
+        DevBuf tmp;
+        SQE_TRY(tmp.ensure(cb + std::max<size_t>(ab, 4)));
+        SQE_HIP(hipMemcpyAsync(tmp.p, host.data(), cb + ab, hipMemcpyHostToDevice, ctx->stream));
+        SQE_TRY(ivf_restore(idx, idx->ivf, tmp.as<float>(), (const int32_t*)((char*)tmp.p + cb), h.n));
+        SQE_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    guard.i = nullptr;
+    *out = idx;
+    return SQE_OK;
 }
 
 int sqe_merge_topk_device(sqe_ctx* ctx, const float* cos_parts_dev, const int64_t* id_parts_dev,

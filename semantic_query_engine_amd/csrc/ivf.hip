@@ -31,6 +31,7 @@ int index_nlist(sqe_index* idx);
 int64_t index_id_base(sqe_index* idx);
 sqe_ctx* index_ctx(sqe_index* idx);
 void index_clear(sqe_index* idx);
+int index_add_restored(sqe_index* idx, const float* x_dev, int64_t n);
 hipStream_t ctx_stream(sqe_ctx* ctx);
 int ctx_cu_count(sqe_ctx* ctx);
 }  // namespace sqe
@@ -503,6 +504,23 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
 
 void ivf_invalidate(IvfState* st) { st->n_assigned = 0; st->lists_dirty = true; }
 sqe_index* ivf_coarse(IvfState* st) { return st->coarse; }
+
+bool ivf_trained(IvfState* st) { return st->trained; }
+
+// sqe_index_load: centroids (normalised, as exported) and the per-row list assignment of a saved index
+int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const int32_t* assign_dev, int64_t n) {
+    const int nlist = index_nlist(base);
+    hipStream_t s = ctx_stream(index_ctx(base));
+    index_clear(st->coarse);
+    SQE_TRY(index_add_restored(st->coarse, centroids_dev, nlist));
+    SQE_TRY(st->assign.ensure((size_t)std::max<int64_t>(n, 1) * 4));
+    if (n > 0) SQE_HIP(hipMemcpyAsync(st->assign.p, assign_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    SQE_HIP(hipStreamSynchronize(s));
+    st->trained = true;
+    st->n_assigned = n;
+    st->lists_dirty = true;
+    return SQE_OK;
+}
 
 // introspection for tests / tools: centroids and assignments as stored
 int ivf_export(sqe_index* base, IvfState* st, float* centroids_host, int32_t* assign_host) {

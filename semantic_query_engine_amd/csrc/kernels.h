@@ -14,6 +14,10 @@ namespace sqe {
 // either may be null.
 int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
                           int bf16_pitch, float* resid_rows, uint32_t* resid_max, hipStream_t stream);
+// Rows that are already normalised (read back from a saved index): out_f32 = x bit for bit, bf16 copy
+// and residual rebuilt (sqe_index_load).
+int launch_restore_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
+                        uint32_t* resid_max, hipStream_t stream);
 // Same, rows scattered to out row ids `rows[i]` (sqe_index_update).
 int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
                                   float* out_f32, bf16_t* out_bf16, int bf16_pitch, uint32_t* resid_max,

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
                                                              float* __restrict__ out_f32,
                                                              bf16_t* __restrict__ out_bf16, int bf16_pitch,
                                                              float* __restrict__ resid_rows,
-                                                             uint32_t* __restrict__ resid_max) {
+                                                             uint32_t* __restrict__ resid_max, int restore) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     }
     ss = wave_sum(ss);
     // np.linalg.norm -> sqrt(sum of squares); then e / (norm + 1e-9) as a true division
-    const float den = sqrtf(ss) + 1e-9f;
+    // restore: rows are stored normalised rows read back from a saved index; they pass through bit
+    // for bit (a division by 1.0f is exact) and only the bf16 copy and the residual are rebuilt
+    const float den = restore ? 1.0f : sqrtf(ss) + 1e-9f;
     const int64_t orow = SCATTER ? rows[row] : row;
     float4* dst = out_f32 ? reinterpret_cast<float4*>(out_f32 + orow * dim) : nullptr;
     uint2* dstb = out_bf16 ? reinterpret_cast<uint2*>(out_bf16 + orow * bf16_pitch) : nullptr;
@@ -70,7 +72,20 @@ int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf
     const int64_t blocks = (n + 3) / 4;
     if (blocks > 0x7fffffffLL) return fail(SQE_ERR_INVALID, "normalize: too many rows for one launch");
     hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       x, (const int64_t*)nullptr, n, dim, out_f32, out_bf16, bf16_pitch, resid_rows, resid_max);
+                       x, (const int64_t*)nullptr, n, dim, out_f32, out_bf16, bf16_pitch, resid_rows, resid_max, 0);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+int launch_restore_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
+                        uint32_t* resid_max, hipStream_t stream) {
+    if (n <= 0) return SQE_OK;
+    if (dim % 4 != 0 || bf16_pitch % 4 != 0 || bf16_pitch < dim)
+        return fail(SQE_ERR_INVALID, "restore: dim and pitch must be multiples of 4, pitch >= dim");
+    const int64_t blocks = (n + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(SQE_ERR_INVALID, "restore: too many rows for one launch");
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       x, (const int64_t*)nullptr, n, dim, out_f32, out_bf16, bf16_pitch, (float*)nullptr, resid_max, 1);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
@@ -82,7 +97,7 @@ int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n
     if (dim % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: dim must be a multiple of 4");
     const int64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(normalize_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       x, rows, n, dim, out_f32, out_bf16, bf16_pitch, (float*)nullptr, resid_max);
+                       x, rows, n, dim, out_f32, out_bf16, bf16_pitch, (float*)nullptr, resid_max, 0);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

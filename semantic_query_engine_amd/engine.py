@@ -115,6 +115,27 @@ class VectorIndex:
         self.handle = h
         ctx._children.add(self)
 
+    @classmethod
+    def load(cls, ctx: Context, path: str) -> "VectorIndex":
+        """Read an index written by ``save`` (sqe_index_load): same rows, bit-identical results."""
+        import struct
+        with open(path, "rb") as f:
+            head = f.read(24)
+        if len(head) < 24 or head[:8] != b"SQEIDX01":
+            raise N.SqeError(-6, f"{path}: not a saved index")
+        _version, dim, _kind, _nlist = struct.unpack_from("<IIII", head, 8)
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.dim = ctx, ctx.lib, int(dim)
+        h = C.c_void_p()
+        N.check(self.lib.sqe_index_load(ctx.handle, path.encode(), C.byref(h)))
+        self.handle = h
+        ctx._children.add(self)
+        return self
+
+    def save(self, path: str) -> None:
+        """Write the stored (normalised) rows, and the IVF centroids/assignments if trained, to a local file."""
+        N.check(self.lib.sqe_index_save(self.handle, path.encode()))
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             if self.ctx.handle:                 # a destroyed context already released the device

@@ -84,6 +84,42 @@ class GpuSearchClient:
         """Shape of ``client.count(index=...)`` (main.py:304-305)."""
         return {"count": len(self.index(index).vectors)}
 
+    # ---- persistence: OpenSearch kept the index across restarts, so ``has_any_data()`` could skip the
+    # rebuild (main.py:422-424).  Here one named index = <dir>/<name>.sqeidx (vectors, sqe_index_save) +
+    # <dir>/<name>.docs.jsonl (row order: {"_id", "doc_id", "text"}).
+    def save_index(self, name: str, directory: str) -> None:
+        import json
+        import os
+        idx = self.index(name)
+        os.makedirs(directory, exist_ok=True)
+        with idx.lock:
+            idx.vectors.save(os.path.join(directory, name + ".sqeidx"))
+            id_of_row = {row: os_id for os_id, row in idx.row_of_id.items()}
+            with open(os.path.join(directory, name + ".docs.jsonl"), "w", encoding="utf-8") as f:
+                for row, src in enumerate(idx.sources):
+                    f.write(json.dumps({"_id": id_of_row[row], "doc_id": src["doc_id"], "text": src["text"]}) + "\n")
+
+    def load_index(self, name: str, directory: str) -> bool:
+        """Load a saved index under ``name``; False when there is nothing to load."""
+        import json
+        import os
+        vp, dp = os.path.join(directory, name + ".sqeidx"), os.path.join(directory, name + ".docs.jsonl")
+        if not (os.path.exists(vp) and os.path.exists(dp)):
+            return False
+        named = _GpuNamedIndex.__new__(_GpuNamedIndex)
+        named.vectors = VectorIndex.load(self.ctx, vp)
+        named.sources, named.row_of_id, named.lock = [], {}, threading.Lock()
+        with open(dp, "r", encoding="utf-8") as f:
+            for row, line in enumerate(f):
+                d = json.loads(line)
+                named.sources.append({"doc_id": d["doc_id"], "text": d["text"]})
+                named.row_of_id[d["_id"]] = row
+        if len(named.sources) != len(named.vectors):
+            raise ValueError(f"{name}: {len(named.sources)} documents for {len(named.vectors)} vectors")
+        with self._lock:
+            self._indexes[name] = named
+        return True
+
 
 class OpenSearchIndexer:
     """Drop-in for the reference class of the same name (main.py:291-373)."""
