@@ -1,0 +1,317 @@
+"""Wire-compatible HTTP front for the GPU path: the subset of the Ollama and
+OpenSearch REST APIs that the reference uses, so the UNMODIFIED ``app/main.py`` can be pointed at it
+with environment variables only (``OLLAMA_API_URL=http://HOST:PORT/api``, ``OPENSEARCH_HOST=HOST``,
+``OPENSEARCH_PORT=PORT``).
+
+    reference call (app/main.py)                       endpoint here
+    ------------------------------------------------   ------------------------------------------
+    :141  POST {OLLAMA_API_URL}/embeddings              POST /api/embeddings      {"embedding": [...]}
+    :258  os_client.info()                              GET  /
+    :261  os_client.indices.exists(name)                HEAD /{index}
+    :282  os_client.indices.create(index, body)         PUT  /{index}
+    :304  client.count(index=...)                       GET|POST /{index}/_count  {"count": n}
+    :342  helpers.bulk(client, actions)                 POST /_bulk (NDJSON, gzip accepted)
+    :361  client.search(index, body={"size","query":{"knn":{"embedding":{"vector","k"}}}})
+                                                        GET|POST /{index}/_search
+
+Scores are the k-NN plugin's nmslib ``cosinesimil`` score ``1 / (2 - cos)``; ``_source`` carries
+``doc_id``, ``text`` and the stored vector, as it did in OpenSearch.  Concurrent embedding requests
+are micro-batched (one encoder call per <= 64 texts or 2 ms) because that is where the GPU path's
+throughput is.
+
+The app is built around two duck-typed objects so that the wire layer can be tested without a GPU:
+``client`` (retrieval.GpuSearchClient: ``index(name)``, ``exists(name)``, ``count(index=)``) and
+``embedder`` (retrieval.Embedder: ``embed(texts) -> float32 [n, dim]``).
+
+    python -m semantic_query_engine_amd.shim --model /models/mxbai-embed-large-v1 --port 9200
+"""
+from __future__ import annotations
+
+import asyncio
+import gzip
+import json
+import time
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+from fastapi import FastAPI, Request, Response
+from fastapi.responses import JSONResponse
+
+_SHARDS = {"total": 1, "successful": 1, "skipped": 0, "failed": 0}
+
+
+class _EmbedBatcher:
+    """Collects concurrent single-text requests into one ``embedder.embed`` call."""
+
+    def __init__(self, embedder, max_batch: int = 64, max_wait_ms: float = 2.0):
+        self.embedder, self.max_batch, self.max_wait = embedder, max_batch, max_wait_ms / 1e3
+        self.queue: "asyncio.Queue" = asyncio.Queue()
+        self.task: Optional[asyncio.Task] = None
+        self.batches = 0
+
+    async def embed(self, text: str) -> np.ndarray:
+        if self.task is None or self.task.done():
+            self.task = asyncio.get_running_loop().create_task(self._run())
+        fut = asyncio.get_running_loop().create_future()
+        await self.queue.put((text, fut))
+        return await fut
+
+    async def _run(self):
+        loop = asyncio.get_running_loop()
+        while True:
+            items = [await self.queue.get()]
+            deadline = loop.time() + self.max_wait
+            while len(items) < self.max_batch:
+                left = deadline - loop.time()
+                if left <= 0:
+                    break
+                try:
+                    items.append(await asyncio.wait_for(self.queue.get(), left))
+                except asyncio.TimeoutError:
+                    break
+            texts = [t for t, _ in items]
+            try:
+                out = await loop.run_in_executor(None, self.embedder.embed, texts)
+                self.batches += 1
+                for (_, fut), row in zip(items, out):
+                    if not fut.done():
+                        fut.set_result(row)
+            except Exception as e:                       # every waiter sees the failure
+                for _, fut in items:
+                    if not fut.done():
+                        fut.set_exception(e)
+
+
+def _os_error(status: int, etype: str, reason: str, **extra) -> JSONResponse:
+    err = {"type": etype, "reason": reason}
+    err.update(extra)
+    return JSONResponse({"error": {"root_cause": [err], **err}, "status": status}, status_code=status)
+
+
+async def _body(request: Request) -> bytes:
+    raw = await request.body()
+    if request.headers.get("content-encoding", "").lower() == "gzip" and raw:
+        raw = gzip.decompress(raw)                       # opensearch-py with http_compress=True (main.py:254)
+    return raw
+
+
+def create_app(client, embedder=None, embed_dim: int = 1024) -> FastAPI:
+    app = FastAPI(title="semantic-query-engine GPU shim")
+    batcher = _EmbedBatcher(embedder) if embedder is not None else None
+    mappings: Dict[str, Any] = {}
+    app.state.batcher = batcher
+
+    # ------------------------------------------------------------------ Ollama
+    @app.post("/api/embeddings")
+    async def ollama_embeddings(request: Request):
+        if batcher is None:
+            return JSONResponse({"error": "no embedding model loaded"}, status_code=500)
+        try:
+            payload = json.loads(await _body(request) or b"{}")
+        except ValueError:
+            return JSONResponse({"error": "invalid JSON"}, status_code=400)
+        if "model" not in payload:
+            return JSONResponse({"error": "model is required"}, status_code=400)
+        prompt = payload.get("prompt", "")
+        if not isinstance(prompt, str) or prompt == "":
+            return JSONResponse({"embedding": []})       # Ollama answers an empty prompt with an empty list
+        vec = await batcher.embed(prompt)
+        return JSONResponse({"embedding": [float(x) for x in vec]})
+
+    # ------------------------------------------------------------------ OpenSearch
+    @app.get("/")
+    async def info():
+        return {"name": "sqe-gpu", "cluster_name": "sqe", "cluster_uuid": "sqe",
+                "version": {"distribution": "opensearch", "number": "2.11.0", "build_type": "sqe-shim",
+                            "lucene_version": "n/a", "minimum_wire_compatibility_version": "7.10.0",
+                            "minimum_index_compatibility_version": "7.0.0"},
+                "tagline": "The OpenSearch Project: https://opensearch.org/"}
+
+    @app.post("/_bulk")
+    @app.put("/_bulk")
+    async def bulk_root(request: Request):
+        return await _bulk(request, None)
+
+    @app.post("/{index}/_bulk")
+    @app.put("/{index}/_bulk")
+    async def bulk_index(index: str, request: Request):
+        return await _bulk(request, index)
+
+    async def _bulk(request: Request, default_index: Optional[str]):
+        t0 = time.perf_counter()
+        lines = [ln for ln in (await _body(request)).split(b"\n") if ln.strip()]
+        # group consecutive documents of one index into one add_embeddings-style device call
+        items: List[Dict[str, Any]] = []
+        pending: Dict[str, List] = {}
+        order: List[tuple] = []
+        i = 0
+        try:
+            while i < len(lines):
+                action = json.loads(lines[i])
+                (op, meta), = action.items()
+                i += 1
+                if op == "delete":
+                    items.append({"delete": {"_index": meta.get("_index", default_index), "_id": meta.get("_id"),
+                                             "status": 400, "error": {"type": "illegal_argument_exception",
+                                                                      "reason": "delete is not supported by this shim"}}})
+                    continue
+                if op not in ("index", "create", "update"):
+                    return _os_error(400, "illegal_argument_exception", f"Malformed action/metadata line, unknown action [{op}]")
+                if i >= len(lines):
+                    return _os_error(400, "illegal_argument_exception", "The bulk request must be terminated by a newline [\\n]")
+                src = json.loads(lines[i])
+                i += 1
+                name = meta.get("_index", default_index)
+                slot = len(items)
+                items.append(None)
+                pending.setdefault(name, []).append((slot, op, meta.get("_id"), src))
+                order.append(name)
+        except ValueError as e:
+            return _os_error(400, "parse_exception", f"malformed bulk body: {e}")
+        errors = False
+        for name, docs in pending.items():
+            res = await asyncio.get_running_loop().run_in_executor(None, _index_docs, client, name, docs, embed_dim)
+            for (slot, op, _id, _src), r in zip(docs, res):
+                items[slot] = {op: r}
+                errors = errors or r["status"] >= 300
+        return {"took": int((time.perf_counter() - t0) * 1e3), "errors": errors, "items": items}
+
+    @app.head("/{index}")
+    async def index_exists(index: str):
+        return Response(status_code=200 if client.exists(index) else 404)
+
+    @app.put("/{index}")
+    async def index_create(index: str, request: Request):
+        if client.exists(index):
+            return _os_error(400, "resource_already_exists_exception", f"index [{index}] already exists", index=index)
+        raw = await _body(request)
+        body = json.loads(raw) if raw.strip() else {}
+        for field, spec in body.get("mappings", {}).get("properties", {}).items():
+            if spec.get("type") == "knn_vector":
+                dim = int(spec.get("dimension", embed_dim))
+                space = spec.get("method", {}).get("space_type", "cosinesimil")
+                if dim != client.dim:
+                    return _os_error(400, "mapper_parsing_exception", f"knn_vector dimension {dim} != {client.dim} of this server")
+                if space != "cosinesimil":
+                    return _os_error(400, "mapper_parsing_exception", f"space_type [{space}] is not served; only cosinesimil")
+        mappings[index] = body
+        client.index(index)
+        return {"acknowledged": True, "shards_acknowledged": True, "index": index}
+
+    @app.get("/{index}/_count")
+    @app.post("/{index}/_count")
+    async def count(index: str):
+        if not client.exists(index):
+            return _os_error(404, "index_not_found_exception", f"no such index [{index}]", index=index)
+        return {"count": client.count(index=index)["count"], "_shards": _SHARDS}
+
+    @app.get("/{index}/_search")
+    @app.post("/{index}/_search")
+    async def search(index: str, request: Request):
+        t0 = time.perf_counter()
+        if not client.exists(index):
+            return _os_error(404, "index_not_found_exception", f"no such index [{index}]", index=index)
+        raw = await _body(request)
+        try:
+            body = json.loads(raw) if raw.strip() else {}
+            knn = body["query"]["knn"]
+            (field, spec), = knn.items()
+            vector = np.asarray(spec["vector"], dtype=np.float32)[None, :]
+            k = int(body.get("size", spec.get("k", 10)))
+            k = max(1, min(k, int(spec.get("k", k)))) if "k" in spec else k
+        except (KeyError, ValueError, TypeError) as e:
+            return _os_error(400, "parsing_exception", f"only {{'query': {{'knn': {{field: {{'vector', 'k'}}}}}}}} is served: {e}")
+        if vector.shape[1] != client.dim:
+            return _os_error(400, "illegal_argument_exception", f"query vector has {vector.shape[1]} dimensions, index has {client.dim}")
+        hits = await asyncio.get_running_loop().run_in_executor(None, _search_hits, client, index, vector, k, field)
+        total = client.count(index=index)["count"]
+        return {"took": int((time.perf_counter() - t0) * 1e3), "timed_out": False, "_shards": _SHARDS,
+                "hits": {"total": {"value": min(total, len(hits)), "relation": "eq"},
+                         "max_score": hits[0]["_score"] if hits else None, "hits": hits}}
+
+    return app
+
+
+def _index_docs(client, name: str, docs, embed_dim: int):
+    """docs: [(slot, op, _id, _source)] of one index -> per-document bulk item bodies, in order."""
+    idx = client.index(name)
+    out = []
+    with idx.lock:
+        new_vecs, new_pos = [], []
+        upd_rows, upd_vecs = [], []
+        for pos, (_slot, op, _id, src) in enumerate(docs):
+            base = {"_index": name, "_id": _id, "_shards": {"total": 1, "successful": 1, "failed": 0}, "_primary_term": 1}
+            emb = src.get("embedding")
+            if _id is None or not isinstance(emb, list) or len(emb) != client.dim:
+                out.append({**base, "status": 400, "error": {"type": "mapper_parsing_exception",
+                                                             "reason": f"_id and an 'embedding' of {client.dim} floats are required"}})
+                continue
+            row = idx.row_of_id.get(_id)
+            rec = {"doc_id": src.get("doc_id"), "text": src.get("text")}
+            if row is None:
+                idx.row_of_id[_id] = len(idx.sources)
+                idx.sources.append(rec)
+                new_vecs.append(emb)
+                out.append({**base, "_version": 1, "result": "created", "_seq_no": len(idx.sources) - 1, "status": 201})
+            elif op == "create":
+                out.append({**base, "status": 409, "error": {"type": "version_conflict_engine_exception",
+                                                             "reason": f"[{_id}]: version conflict, document already exists"}})
+            else:
+                idx.sources[row] = rec
+                upd_rows.append(row)
+                upd_vecs.append(emb)
+                out.append({**base, "_version": 2, "result": "updated", "_seq_no": row, "status": 200})
+        if new_vecs:
+            idx.vectors.add(np.asarray(new_vecs, dtype=np.float32))
+        if upd_rows:
+            idx.vectors.update(np.asarray(upd_rows, np.int64), np.asarray(upd_vecs, dtype=np.float32))
+    return out
+
+
+def _search_hits(client, name: str, vector: np.ndarray, k: int, field: str):
+    """Row 0 only, exact cosine order, ``_score = 1 / (2 - cos)`` (what OpenSearchIndexer.search returns, with _id)."""
+    idx = client.index(name)
+    with idx.lock:
+        cos, ids = idx.vectors.search(np.ascontiguousarray(vector[0:1], dtype=np.float32), k)
+        rows = [int(r) for r in ids[0] if r >= 0]
+        embs = idx.vectors.get_rows(rows) if rows else np.zeros((0, client.dim), np.float32)
+        rev = getattr(idx, "_id_of_row", None)
+        if rev is None or len(rev) != len(idx.row_of_id):
+            rev = {row: os_id for os_id, row in idx.row_of_id.items()}
+            idx._id_of_row = rev
+        hits = []
+        for j, row in enumerate(rows):
+            src = idx.sources[row]
+            hits.append({"_index": name, "_id": rev.get(row), "_score": float(1.0 / (2.0 - float(cos[0, j]))),
+                         "_source": {"doc_id": src["doc_id"], "text": src["text"], field: [float(x) for x in embs[j]]}})
+    return hits
+
+
+def main(argv=None) -> None:
+    import argparse
+
+    import uvicorn
+
+    from .retrieval import GpuSearchClient, default_context
+    from .weights import embedder_from_local
+
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--model", help="local Hugging Face directory or GGUF file of the embedding model (never a model name)")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=9200)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--load", help="directory with indexes written by GpuSearchClient.save_index")
+    args = ap.parse_args(argv)
+    ctx = default_context()
+    client = GpuSearchClient(ctx, dim=args.dim)
+    if args.load:
+        import glob
+        import os
+        for p in glob.glob(os.path.join(args.load, "*.sqeidx")):
+            client.load_index(os.path.basename(p)[:-len(".sqeidx")], args.load)
+    embedder = embedder_from_local(ctx, args.model) if args.model else None
+    uvicorn.run(create_app(client, embedder, args.dim), host=args.host, port=args.port, log_level="warning")
+
+
+if __name__ == "__main__":
+    main()
