@@ -66,6 +66,19 @@ __device__ __forceinline__ uint64_t make_key(float score, uint32_t row) {
 __device__ __forceinline__ uint32_t key_row(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)key; }
 __device__ __forceinline__ float key_score(uint64_t key) { return f32_from_orderable((uint32_t)(key >> 32)); }
 
+// global -> LDS copy of 16 B per lane (LDS destination = wave-uniform base + lane * 16) as inline asm.
+// Through the builtin, hipcc tracks every LDS-DMA piece as a pending write to LDS and puts
+// s_waitcnt vmcnt(0) in front of the next LDS read it sees, which drains the ring; kernels that keep
+// stages in flight across LDS reads issue their pieces here and count their own waits.
+__device__ __forceinline__ void lds_dma16(const char* src, char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_sc1(const char* src, char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(src), "s"(dst) : "memory");
+}
+
 // Lane id recomputed on the spot (2 VALU ops).  Used in rarely-run blocks of the pipelined
 // kernels so that no per-lane address has to stay alive across the main loop: a spilled one
 // is reloaded with a scratch load, whose compiler-inserted vmcnt(0) drains the DMA queue.

@@ -26,6 +26,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace sqe {
@@ -69,6 +71,9 @@ struct GemmArgs {
     void* out;            // bf16 [T_pad, N] or fp32 [T_pad, N] (EPI_RESID)
     int N, K, T;          // T = valid token rows
     int n_tiles;
+    int splits;           // split-K factor (ring kernel, EPI_RESID only): split s writes its partial sum to
+    size_t split_stride;  //   out + s * split_stride floats; bias and residual are added by split 0
+    int t_tiles;
 };
 
 // Block tile: (2*FM*16) output features x (4*FN*16) tokens, 8 waves as 2 (features) x 4 (tokens).
@@ -173,27 +178,187 @@ int launch_gemm_cfg(const GemmArgs& a, int t_pad, hipStream_t stream) {
     return SQE_OK;
 }
 
-// 256x256 tiles when there are enough tokens to fill the chip with them, 128x128 otherwise
+// Small-batch form: 128 x 128 tiles, 4-stage LDS ring (3 K steps of DMA in flight, counted waits, pieces
+// issued through lds_dma16 so hipcc adds no vmcnt(0) of its own), optional split-K.  With a few
+// hundred tokens a GEMM has fewer tiles than the chip has CUs and every K step of the two-stage kernel
+// above exposes a full memory round trip; here the round trips overlap and the K loop of the two
+// N = hidden GEMMs is cut into `splits` workgroups whose fp32 partial sums the LayerNorm kernels add up
+// (deterministic, no atomics).
 template <int EPI>
-int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream) {
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
+    constexpr int FM = 4, FN = 2, NST = 4;
+    constexpr int BNW = 2 * FM * 16, BT = 4 * FN * 16;
+    constexpr int STAGE = (BNW + BT) * ROWB;
+    constexpr int PIECES = (BNW / 8 + BT / 8) / 8;        // per wave per stage
+    static_assert(PIECES * (NST - 2) == 8, "counted wait below");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = p.n_tiles * p.t_tiles;
+    const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int nt = tile % p.n_tiles, tt = tile / p.n_tiles;
+    const int n0 = nt * BNW, t0 = tt * BT;
+    const size_t ld = (size_t)p.K * 2;
+    const int KS = p.K / 64 / p.splits;
+    const char* wbase = reinterpret_cast<const char*>(p.W) + (size_t)n0 * ld + (size_t)split * KS * ROWB;
+    const char* xbase = reinterpret_cast<const char*>(p.X) + (size_t)t0 * ld + (size_t)split * KS * ROWB;
+
+    // per-lane source offsets of this wave's pieces (2 of W, 2 of X): rows 8*(wave + 8*i) + (lane >> 3)
+    unsigned off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave + 8 * i) * 8 + (lane >> 3);
+        off[i] = (unsigned)(r * ld) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    auto issue = [&](int ks) {
+        char* buf = smem + (ks % NST) * STAGE;
+        const char* ws = wbase + (size_t)ks * ROWB;
+        const char* xs = xbase + (size_t)ks * ROWB;
+        lds_dma16(ws + off[0], buf + wave * 1024);
+        lds_dma16(ws + off[1], buf + (wave + 8) * 1024);
+        lds_dma16(xs + off[0], buf + BNW * ROWB + wave * 1024);
+        lds_dma16(xs + off[1], buf + BNW * ROWB + (wave + 8) * 1024);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < NST - 1 && s < KS; ++s) issue(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool more = ks + NST - 1 < KS;
+        if (more) issue(ks + NST - 1);        // into the buffer K step ks - 1 used (all waves passed its barrier)
+        const char* tA = smem + (ks % NST) * STAGE;
+        const char* tB = tA + BNW * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[FM], b[FN];
+            const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = frag(tA, wm * (FM * 16) + i * 16 + (lane & 15), c);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = frag(tB, wn * (FN * 16) + j * 16 + (lane & 15), c);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        // K step ks + 1 landed; the two younger stages stay in flight
+        if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (as gemm_bf16_kernel; split-K partial sums for EPI_RESID)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int n = n0 + wm * (FM * 16) + i * 16 + (lane >> 4) * 4;
+        float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (EPI == EPI_RESID && split != 0) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int t = t0 + wn * (FN * 16) + j * 16 + (lane & 15);
+            if (t >= p.T) continue;
+            float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+            const size_t o = (size_t)t * p.N + n;
+            if (EPI == EPI_RESID) {
+                if (split == 0) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o);
+                    v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
+                    v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
+                }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)split * p.split_stride + o) =
+                    make_float4(v0, v1, v2, v3);
+            } else {
+                if (EPI == EPI_GELU) {
+                    v0 = 0.5f * v0 * (1.0f + erff(v0 * 0.70710678118654752f));
+                    v1 = 0.5f * v1 * (1.0f + erff(v1 * 0.70710678118654752f));
+                    v2 = 0.5f * v2 * (1.0f + erff(v2 * 0.70710678118654752f));
+                    v3 = 0.5f * v3 * (1.0f + erff(v3 * 0.70710678118654752f));
+                }
+                uint2 w2;
+                w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_stride, int* splits_out, hipStream_t stream) {
+    constexpr int LDS = 4 * (128 + 128) * ROWB;
+    GemmArgs p = a;
+    p.n_tiles = a.N / 128;
+    p.t_tiles = t_pad / 128;
+    const int tiles = p.n_tiles * p.t_tiles;
+    int splits = 1;
+    if (EPI == EPI_RESID) {
+        const int ks = a.K / 64;
+        while (splits < 4 && tiles * splits * 2 <= cu_count && ks % (splits * 2) == 0 && ks / (splits * 2) >= 4) splits *= 2;
+    }
+    p.splits = splits;
+    p.split_stride = split_stride;
+    if (splits_out) *splits_out = splits;
+    auto kern = gemm_ring_kernel<EPI>;
+    static bool attr = false;
+    if (!attr) {
+        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), LDS, stream, p);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+// 256x256 tiles when there are enough tokens to fill the chip with them, the 128x128 ring kernel otherwise.
+// *splits_out = number of fp32 partial sums written (EPI_RESID), `split_stride` floats apart.
+template <int EPI>
+int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, size_t split_stride = 0,
+                int* splits_out = nullptr) {
     if (a.N % 128 != 0 || a.K % 64 != 0) return fail(SQE_ERR_INVALID, "encoder gemm: N % 128 or K % 64");
+    if (splits_out) *splits_out = 1;
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
-    if (big) return launch_gemm_cfg<8, 4, EPI>(a, t_pad, stream);
-    return launch_gemm_cfg<4, 2, EPI>(a, t_pad, stream);
+    if (big) {
+        GemmArgs p = a;
+        p.splits = 1; p.split_stride = 0; p.t_tiles = 0;
+        return launch_gemm_cfg<8, 4, EPI>(p, t_pad, stream);
+    }
+    return launch_gemm_ring<EPI>(a, t_pad, cu_count, split_stride, splits_out, stream);
 }
 
 // ------------------------------------------------------------------ LayerNorm family
 // one wave per row; H % 4 == 0; two passes over registers-or-cache (row <= 16 KiB)
-__device__ __forceinline__ void ln_stats(const float* row, int H, int lane, float& mean, float& rstd, float eps) {
+// row element i = sum over the nsplit split-K partial sums (stride floats apart); nsplit = 1: plain row
+__device__ __forceinline__ float4 ln_load(const float* row, int i, int nsplit, size_t stride) {
+    float4 v = *reinterpret_cast<const float4*>(row + i);
+    for (int s = 1; s < nsplit; ++s) {
+        const float4 w = *reinterpret_cast<const float4*>(row + (size_t)s * stride + i);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void ln_stats(const float* row, int H, int lane, float& mean, float& rstd, float eps,
+                                         int nsplit = 1, size_t stride = 0) {
     float s = 0.f;
     for (int i = lane * 4; i < H; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        const float4 v = ln_load(row, i, nsplit, stride);
         s += v.x + v.y + v.z + v.w;
     }
     mean = wave_sum(s) / (float)H;
     float q = 0.f;
     for (int i = lane * 4; i < H; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        const float4 v = ln_load(row, i, nsplit, stride);
         const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
         q += a * a + b * b + c * c + d * d;
     }
@@ -202,15 +367,15 @@ __device__ __forceinline__ void ln_stats(const float* row, int H, int lane, floa
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ g,
                                                         const float* __restrict__ b, bf16_t* __restrict__ out,
-                                                        int T, int H, float eps) {
+                                                        int T, int H, float eps, int nsplit, size_t stride) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
     const float* x = in + (size_t)row * H;
     float mean, rstd;
-    ln_stats(x, H, lane, mean, rstd, eps);
+    ln_stats(x, H, lane, mean, rstd, eps, nsplit, stride);
     for (int i = lane * 4; i < H; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float4 v = ln_load(x, i, nsplit, stride);
         const float4 gg = *reinterpret_cast<const float4*>(g + i);
         const float4 bb = *reinterpret_cast<const float4*>(b + i);
         uint2 w;
@@ -223,15 +388,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // E7: LayerNorm of the CLS row of every sequence, fp32 out [B, H]
 __global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ in, const float* __restrict__ g,
                                                       const float* __restrict__ b, float* __restrict__ out,
-                                                      int B, int S, int H, float eps) {
+                                                      int B, int S, int H, float eps, int nsplit, size_t stride) {
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seq >= B) return;
     const float* x = in + (size_t)seq * S * H;
     float mean, rstd;
-    ln_stats(x, H, lane, mean, rstd, eps);
+    ln_stats(x, H, lane, mean, rstd, eps, nsplit, stride);
     for (int i = lane * 4; i < H; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float4 v = ln_load(x, i, nsplit, stride);
         const float4 gg = *reinterpret_cast<const float4*>(g + i);
         const float4 bb = *reinterpret_cast<const float4*>(b + i);
         *reinterpret_cast<float4*>(out + (size_t)seq * H + i) =
@@ -454,6 +619,23 @@ struct sqe_encoder {
     // workspace
     DevMem x, x1, qkv, att, hbuf, pre, ids, lens, out;
     int t_cap = 0;
+    // Launch-bound regime (a query batch is ~170 short kernels): the forward pass of a given
+    // (B, S, buffers) is captured once into a hipGraph and replayed.  A key is captured the second
+    // time it is seen, so callers that pass fresh buffers every time just run eagerly.
+    struct GraphEntry {
+        int B = 0, S = 0;
+        const void* ids = nullptr; const void* lens = nullptr; void* out = nullptr;
+        int seen = 0;
+        uint64_t last_use = 0;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    bool use_graphs = true;
+    ~sqe_encoder() {
+        for (auto& g : graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    }
 };
 
 // sqe_ctx internals needed here (defined in api.hip)
@@ -497,6 +679,10 @@ int sqe_encoder_create(sqe_ctx* ctx, const sqe_bert_cfg* cfg, sqe_encoder** out)
     e->ctx = ctx;
     e->cfg = *cfg;
     for (int l = 0; l < cfg->layers; ++l) e->layers.emplace_back(new sqe_layer);
+    {
+        const char* g = getenv("SQE_ENC_GRAPH");          // SQE_ENC_GRAPH=0: always launch kernel by kernel
+        e->use_graphs = !(g && g[0] == '0');
+    }
     *out = e.release();
     return SQE_OK;
 }
@@ -569,6 +755,9 @@ int sqe_encoder_finalize(sqe_encoder* enc) {
     return SQE_OK;
 }
 
+static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev,
+                          int t_pad, hipStream_t st);
+
 int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev) {
     if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
     if (!enc->finalized) return fail(SQE_ERR_STATE, "sqe_encode: encoder weights not finalized");
@@ -583,12 +772,15 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
     const int t_pad = (T + 255) / 256 * 256;
     // +64 rows: the attention kernel stages whole 64-key tiles, which may run past the last sequence
     if (t_pad > enc->t_cap) {
+        for (auto& g : enc->graphs)                       // recorded launches point into the old workspace
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        enc->graphs.clear();
         SQE_TRY(enc->x.alloc((size_t)(t_pad + 64) * H * 2));
         SQE_TRY(enc->x1.alloc((size_t)(t_pad + 64) * H * 2));
         SQE_TRY(enc->att.alloc((size_t)(t_pad + 64) * H * 2));
         SQE_TRY(enc->qkv.alloc((size_t)(t_pad + 64) * 3 * H * 2));
         SQE_TRY(enc->hbuf.alloc((size_t)(t_pad + 64) * I * 2));
-        SQE_TRY(enc->pre.alloc((size_t)t_pad * H * 4));
+        SQE_TRY(enc->pre.alloc((size_t)t_pad * H * 4 * 4));     // up to 4 split-K partial sums
         SQE_HIP(hipMemsetAsync(enc->x.p, 0, (size_t)(t_pad + 64) * H * 2, st));
         SQE_HIP(hipMemsetAsync(enc->x1.p, 0, (size_t)(t_pad + 64) * H * 2, st));
         SQE_HIP(hipMemsetAsync(enc->att.p, 0, (size_t)(t_pad + 64) * H * 2, st));
@@ -596,8 +788,61 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
         SQE_HIP(hipMemsetAsync(enc->hbuf.p, 0, (size_t)(t_pad + 64) * I * 2, st));
         enc->t_cap = t_pad;
     }
+    // ---- replay / capture (small batches only: above ~8k tokens the kernels are long enough)
+    constexpr int GRAPH_MAX_TOKENS = 8192;
+    constexpr size_t GRAPH_CACHE = 8;
+    sqe_encoder::GraphEntry* ge = nullptr;
+    if (enc->use_graphs && t_pad <= GRAPH_MAX_TOKENS) {
+        for (auto& e : enc->graphs)
+            if (e.B == B && e.S == S && e.ids == ids_dev && e.lens == lens_dev && e.out == out_dev) ge = &e;
+        if (!ge) {
+            if (enc->graphs.size() >= GRAPH_CACHE) {              // evict the least recently used entry
+                size_t victim = 0;
+                for (size_t i = 1; i < enc->graphs.size(); ++i)
+                    if (enc->graphs[i].last_use < enc->graphs[victim].last_use) victim = i;
+                if (enc->graphs[victim].exec) (void)hipGraphExecDestroy(enc->graphs[victim].exec);
+                enc->graphs.erase(enc->graphs.begin() + victim);
+            }
+            sqe_encoder::GraphEntry fresh;
+            fresh.B = B; fresh.S = S; fresh.ids = ids_dev; fresh.lens = lens_dev; fresh.out = out_dev;
+            enc->graphs.push_back(fresh);
+            ge = &enc->graphs.back();
+        }
+        ge->last_use = ++enc->graph_clock;
+        ++ge->seen;
+        if (ge->exec) {
+            SQE_HIP(hipGraphLaunch(ge->exec, st));
+            return SQE_OK;
+        }
+    }
+    const bool capture = ge && ge->seen >= 2;
+    if (capture) SQE_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = encode_enqueue(enc, ids_dev, lens_dev, B, S, out_dev, t_pad, st);
+    if (capture) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc != SQE_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess || !graph) return fail(SQE_ERR_HIP, std::string("encoder graph capture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { ge->exec = nullptr; return fail(SQE_ERR_HIP, std::string("encoder graph instantiate: ") + hipGetErrorString(e)); }
+        SQE_HIP(hipGraphLaunch(ge->exec, st));
+    }
+    return rc;
+}
+
+// the forward pass as a sequence of launches on `st` (run directly, or recorded by a stream capture)
+static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev,
+                          int t_pad, hipStream_t st) {
+    const sqe_bert_cfg& c = enc->cfg;
+    const int H = c.hidden, I = c.inter;
+    const int T = B * S;
     const int cus = ctx_cu_count(enc->ctx);
     const int rows4 = (T + 3) / 4;
+    const size_t pstride = (size_t)t_pad * H;             // floats between split-K partial sums in `pre`
     hipLaunchKernelGGL(embed_ln_kernel, dim3(rows4), dim3(256), 0, st, ids_dev, enc->word.as<bf16_t>(), enc->pos.as<bf16_t>(),
                        enc->type.as<bf16_t>(), enc->emb_g.as<float>(), enc->emb_b.as<float>(), enc->pre.as<float>(),
                        enc->x.as<bf16_t>(), T, S, H, c.vocab_size, c.ln_eps);
@@ -617,9 +862,10 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
         // E4: output projection + residual, LayerNorm
         a.W = L.w_o.as<bf16_t>(); a.X = enc->att.as<bf16_t>(); a.bias = L.b_o.as<float>(); a.resid = enc->x.as<bf16_t>();
         a.out = enc->pre.p; a.N = H; a.K = H;
-        SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st));
+        int ns = 1;
+        SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st, pstride, &ns));
         hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln1_g.as<float>(),
-                           L.ln1_b.as<float>(), enc->x1.as<bf16_t>(), T, H, c.ln_eps);
+                           L.ln1_b.as<float>(), enc->x1.as<bf16_t>(), T, H, c.ln_eps, ns, pstride);
         // E5: FFN up + GELU
         a.W = L.w_1.as<bf16_t>(); a.X = enc->x1.as<bf16_t>(); a.bias = L.b_1.as<float>(); a.resid = nullptr;
         a.out = enc->hbuf.p; a.N = I; a.K = H;
@@ -627,13 +873,13 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
         // E6: FFN down + residual, LayerNorm (the last layer's LayerNorm is done by the pooling kernel in fp32)
         a.W = L.w_2.as<bf16_t>(); a.X = enc->hbuf.as<bf16_t>(); a.bias = L.b_2.as<float>(); a.resid = enc->x1.as<bf16_t>();
         a.out = enc->pre.p; a.N = H; a.K = I;
-        SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st));
+        SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st, pstride, &ns));
         if (l + 1 < c.layers) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
-                               L.ln2_b.as<float>(), enc->x.as<bf16_t>(), T, H, c.ln_eps);
+                               L.ln2_b.as<float>(), enc->x.as<bf16_t>(), T, H, c.ln_eps, ns, pstride);
         } else {
             hipLaunchKernelGGL(pool_ln_kernel, dim3((B + 3) / 4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
-                               L.ln2_b.as<float>(), out_dev, B, S, H, c.ln_eps);
+                               L.ln2_b.as<float>(), out_dev, B, S, H, c.ln_eps, ns, pstride);
         }
         SQE_HIP(hipGetLastError());
     }

@@ -114,19 +114,6 @@ struct Filter {
 // host: kernel argument block from a plan (scan.hip)
 ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a);
 
-// global -> LDS copy of 16 B per lane (LDS destination = wave-uniform base + lane * 16) as inline asm.
-// Through the builtin, hipcc tracks every LDS-DMA piece as a pending write to LDS and puts
-// s_waitcnt vmcnt(0) in front of the next LDS read it sees, which drains the ring; kernels that keep
-// stages in flight across LDS reads issue their pieces here and count their own waits.
-__device__ __forceinline__ void lds_dma16(const char* src, char* lds_wave_base) {
-    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
-}
-__device__ __forceinline__ void lds_dma16_sc1(const char* src, char* lds_wave_base) {
-    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(src), "s"(dst) : "memory");
-}
-
 __device__ __forceinline__ void store_sc1_u32(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
