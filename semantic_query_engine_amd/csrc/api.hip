@@ -225,6 +225,8 @@ int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const
 // accessors used by encoder.hip / ivf.hip (sqe_ctx and sqe_index are defined in this file only)
 namespace sqe {
 float* index_master(sqe_index* idx) { return idx->master; }
+const bf16_t* index_scan(sqe_index* idx) { return idx->scan; }
+int index_pitch(sqe_index* idx) { return idx->pitch; }
 int64_t index_rows(sqe_index* idx) { return idx->n; }
 int index_dim(sqe_index* idx) { return idx->dim; }
 int index_nlist(sqe_index* idx) { return idx->nlist; }

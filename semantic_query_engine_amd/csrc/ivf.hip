@@ -25,6 +25,8 @@ struct sqe_ctx;
 // internal hooks implemented in api.hip
 namespace sqe {
 float* index_master(sqe_index* idx);
+const bf16_t* index_scan(sqe_index* idx);
+int index_pitch(sqe_index* idx);
 int64_t index_rows(sqe_index* idx);
 int index_dim(sqe_index* idx);
 int index_nlist(sqe_index* idx);
@@ -232,10 +234,148 @@ __global__ __launch_bounds__(256) void ivf_list_scan_kernel(const float* __restr
     }
 }
 
-// per query: exact top-k over the score strips of its probed lists (key = score desc, row id asc)
+// S6 (MFMA form): one workgroup per list.  Rows of the list are gathered from the bf16 scan copy by
+// their ids (the LDS-DMA takes a per-lane source address, so a gather costs nothing extra), 256 rows x
+// up to 64 of the queries that probe the list per tile, v_mfma_f32_16x16x32_bf16, 3-stage LDS ring
+// (two K steps in flight).  Scores go to the same per-(query, probe) strips as the fp32 kernel above;
+// ivf_select_kernel re-scores the best of them in fp32.  HBM-bound: every probed row is read once per
+// group of 64 queries, at 2 bytes per element.
+constexpr int LS_ROWS = 256, LS_Q = 64, LS_NST = 3, LS_SEG = 4096;
+constexpr int LS_STAGE = (LS_ROWS + LS_Q) * 128;
+constexpr int LS_LDS = LS_NST * LS_STAGE + LS_SEG * 4 + LS_Q * 4;
+
+__device__ __forceinline__ void global_store_f4_asm(float* p, f32x4 v) {
+    // inline asm: a store hipcc knows about would make it guard the ring's invisible DMA pieces with vmcnt(0)
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(512) void ivf_list_scan_mfma_kernel(const bf16_t* __restrict__ scan, int pitch,
+                                                                 const bf16_t* __restrict__ qb, int qpitch,
+                                                                 const int* __restrict__ order,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 const int* __restrict__ lcount, const int* __restrict__ lq,
+                                                                 int cap, int nprobe, int K, int max_len,
+                                                                 float* __restrict__ pair_scores) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sorder = reinterpret_cast<int*>(smem + LS_NST * LS_STAGE);
+    int* spair = sorder + LS_SEG;
+    const int L = blockIdx.x;
+    const int m = min(lcount[L], cap);
+    const int64_t off = offsets[L];
+    const int len_all = (int)(offsets[L + 1] - off);
+    if (m == 0 || len_all == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KS = K / 64;
+    const char* scan_b = reinterpret_cast<const char*>(scan);
+    const char* qb_b = reinterpret_cast<const char*>(qb);
+    const int chunk_lo = lane & 7, r_in_piece = lane >> 3;
+
+    for (int seg0 = 0; seg0 < len_all; seg0 += LS_SEG) {
+        const int len = min(LS_SEG, len_all - seg0);
+        __syncthreads();
+        for (int i = tid; i < len; i += 512) sorder[i] = order[off + seg0 + i];
+        const int n_tiles = (len + LS_ROWS - 1) / LS_ROWS;
+        for (int g0 = 0; g0 < m; g0 += LS_Q) {
+            const int gq = min(LS_Q, m - g0);
+            __syncthreads();
+            if (tid < LS_Q) spair[tid] = lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
+            __syncthreads();
+            // this lane's query row of the one Q piece its wave issues per stage
+            const int qj = wave * 8 + r_in_piece;
+            const size_t qoff = (size_t)(spair[qj] / nprobe) * qpitch + ((chunk_lo ^ ((qj >> 1) & 7)) << 4);
+
+            const int total = n_tiles * KS;
+            int i_tile = -1, i_ks = KS - 1;                 // issue cursor
+            size_t aoff[4];
+            auto issue = [&](int s) {
+                if (++i_ks == KS) {                         // the cursor enters a new tile: its rows' addresses
+                    i_ks = 0;
+                    ++i_tile;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = (wave + 8 * it) * 8 + r_in_piece;
+                        const int rr = min(i_tile * LS_ROWS + r, len - 1);          // rows past the end repeat the last one
+                        aoff[it] = (size_t)sorder[rr] * pitch + ((chunk_lo ^ ((r >> 1) & 7)) << 4);
+                    }
+                }
+                char* buf = smem + (s % LS_NST) * LS_STAGE;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) lds_dma16(scan_b + aoff[it] + (size_t)i_ks * 128, buf + (wave + 8 * it) * 1024);
+                lds_dma16(qb_b + qoff + (size_t)i_ks * 128, buf + LS_ROWS * 128 + wave * 1024);
+            };
+            for (int s = 0; s < LS_NST - 1 && s < total; ++s) issue(s);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+
+            f32x4 acc[2][4];
+            int ks = 0, tile = 0;
+            for (int s = 0; s < total; ++s) {
+                const bool more = s + LS_NST - 1 < total;
+                if (more) issue(s + LS_NST - 1);
+                if (ks == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const char* tA = smem + (s % LS_NST) * LS_STAGE;
+                const char* tB = tA + LS_ROWS * 128;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 a[2], b[4];
+                    const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int r = wave * 32 + i * 16 + (lane & 15);
+                        a[i] = *reinterpret_cast<const bf16x8*>(tA + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = j * 16 + (lane & 15);
+                        b[j] = *reinterpret_cast<const bf16x8*>(tB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+                if (++ks == KS) {
+                    // scores of this tile: a lane holds 4 consecutive rows of one query per fragment
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = j * 16 + (lane & 15);
+                        if (col < gq) {
+                            float* strip = pair_scores + (size_t)spair[col] * max_len + seg0 + tile * LS_ROWS;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int r = wave * 32 + i * 16 + (lane >> 4) * 4;
+                                if (tile * LS_ROWS + r < len)      // len and max_len are padded reads, not padded strips:
+                                    global_store_f4_asm(strip + r, acc[i][j]);
+                            }
+                        }
+                    }
+                    ks = 0;
+                    ++tile;
+                }
+                if (more) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// per query: the kp best scan scores over the strips of its probed lists, re-scored in fp32 against the
+// master, then the top-k by (fp32 cosine desc, row id asc)
 __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
                                                          const int* __restrict__ order, const float* __restrict__ pair_scores,
-                                                         int nprobe, int max_len, int k, int64_t id_base,
+                                                         int nprobe, int max_len, int k, int kp, int64_t id_base,
+                                                         const float* __restrict__ master, const float* __restrict__ qn, int K,
                                                          float* __restrict__ cos_out, int64_t* __restrict__ id_out) {
     __shared__ int hist[256];
     __shared__ int scratch[4];
@@ -251,8 +391,8 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         if (L >= 0) total += (int)(offsets[L + 1] - offsets[L]);
     }
     uint64_t prefix = 0;
-    int remaining = k;
-    const bool all = total <= k;
+    int remaining = kp;
+    const bool all = total <= kp;
     for (int byte = 7; byte >= 0 && !all; --byte) {
         hist[tid] = 0;
         __syncthreads();
@@ -303,15 +443,36 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         }
     }
     __syncthreads();
-    const int m = min(scratch[2], k);
+    const int m = min(scratch[2], kp);
+    // fp32 re-score of the kept rows (one wave per row), then rank by the exact cosines
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const float4* qv = reinterpret_cast<const float4*>(qn + (size_t)q * K);
+        const int nvec = K >> 2;
+        for (int e = wave; e < m; e += 4) {
+            const uint32_t row = key_row(top[e]);
+            const float4* rv = reinterpret_cast<const float4*>(master + (size_t)row * K);
+            float s = 0.f;
+            for (int v4 = lane; v4 < nvec; v4 += 64) {
+                const float4 a = rv[v4], b = qv[v4];
+                s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+            }
+            s = wave_sum(s) + 0.0f;
+            if (lane == 0) top[e] = make_key(s, row);
+        }
+    }
+    __syncthreads();
+    const int mk = min(m, k);
     for (int i = tid; i < m; i += 256) {
         const uint64_t ki = top[i];
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += top[j] > ki ? 1 : 0;
-        cos_out[(size_t)q * k + rank] = key_score(ki);
-        id_out[(size_t)q * k + rank] = (int64_t)key_row(ki) + id_base;
+        if (rank < k) {
+            cos_out[(size_t)q * k + rank] = key_score(ki);
+            id_out[(size_t)q * k + rank] = (int64_t)key_row(ki) + id_base;
+        }
     }
-    for (int i = m + tid; i < k; i += 256) {
+    for (int i = mk + tid; i < k; i += 256) {
         cos_out[(size_t)q * k + i] = -INFINITY;
         id_out[(size_t)q * k + i] = -1;
     }
@@ -333,7 +494,7 @@ struct IvfState {
     int64_t n_assigned = 0;            // rows of the base index that have an assignment
     int max_len = 0;
     Buf centroids, assign, order, offsets, counts, cursor;   // device
-    Buf qn, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
+    Buf qn, qb, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
 };
 
@@ -479,25 +640,42 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     hipStream_t s = ctx_stream(ctx);
     SQE_TRY(ivf_rows_added(base, st));
     if (st->lists_dirty) SQE_TRY(ivf_build_lists(base, st));
-    const int max_len = std::max(st->max_len, 1);
+    const int max_len = (std::max(st->max_len, 1) + 3) / 4 * 4;        // strips are written 4 floats at a time
+    const int pitch = index_pitch(base);
+    const int kp = std::min(MAX_KP, std::max(32, 4 * k));
     SQE_TRY(st->qn.ensure((size_t)B * dim * 4));
+    SQE_TRY(st->qb.ensure((size_t)(B + LS_Q) * pitch));
     SQE_TRY(st->probes_cos.ensure((size_t)B * nprobe * 4));
     SQE_TRY(st->probes_ids.ensure((size_t)B * nprobe * 8));
     SQE_TRY(st->lcount.ensure((size_t)nlist * 4));
     SQE_TRY(st->lq.ensure((size_t)nlist * B * 4));
     SQE_TRY(st->pair_scores.ensure((size_t)B * nprobe * max_len * 4));
-    SQE_TRY(launch_normalize_rows(q_dev, B, dim, st->qn.as<float>(), nullptr, dim, nullptr, nullptr, s));
+    SQE_TRY(launch_normalize_rows(q_dev, B, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
     // S5: coarse quantise
     SQE_TRY(sqe_index_search_device(st->coarse, st->qn.as<float>(), B, nprobe, 0, st->probes_cos.as<float>(), st->probes_ids.as<int64_t>()));
     SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)nlist * 4, s));
     hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
                        st->lcount.as<int>(), st->lq.as<int>(), B);
     // S6: list scan
-    hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, index_master(base), st->qn.as<float>(), st->order.as<int>(),
-                       st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
-                       st->pair_scores.as<float>());
+    static const bool fp32_lists = [] { const char* e = getenv("SQE_IVF_FP32"); return e && e[0] == '1'; }();
+    if (fp32_lists) {
+        hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, index_master(base), st->qn.as<float>(), st->order.as<int>(),
+                           st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                           st->pair_scores.as<float>());
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS));
+            attr = true;
+        }
+        hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, index_scan(base), pitch, st->qb.as<bf16_t>(),
+                           pitch, st->order.as<int>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe,
+                           dim, max_len, st->pair_scores.as<float>());
+    }
     hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
-                       st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, index_id_base(base), cos_out, id_out);
+                       st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, index_id_base(base),
+                       index_master(base), st->qn.as<float>(), dim, cos_out, id_out);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
