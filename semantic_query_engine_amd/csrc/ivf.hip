@@ -390,10 +390,97 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         const int64_t L = probes[(size_t)q * nprobe + p];
         if (L >= 0) total += (int)(offsets[L + 1] - offsets[L]);
     }
+    // ---- fast path: a threshold from a strided sample, ONE pass over the strips that collects every key
+    // at or above it, exact top-kp among the few collected.  (The general path below walks the strips
+    // eight times; it remains the fallback when the sample misjudges the tail.)
+    constexpr int SAMPLE_CAP = 8704, COLLECT_CAP = 1024;
+    __shared__ uint32_t sample[SAMPLE_CAP];
+    __shared__ uint64_t coll[COLLECT_CAP];
+    bool done = false;
+    if (total > COLLECT_CAP) {
+        const int stride = (total + 8191) / 8192;
+        if (tid == 0) { scratch[0] = 0; scratch[2] = 0; }
+        __syncthreads();
+        for (int p = 0; p < nprobe; ++p) {
+            const int64_t L = probes[(size_t)q * nprobe + p];
+            if (L < 0) continue;
+            const int len = (int)(offsets[L + 1] - offsets[L]);
+            const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
+            for (int i = tid * stride + (p % stride); i < len; i += 256 * stride) {
+                const float sc = strip[i];
+                if (sc != sc) continue;
+                const int slot = atomicAdd(&scratch[0], 1);
+                if (slot < SAMPLE_CAP) sample[slot] = f32_orderable(sc + 0.0f);
+            }
+        }
+        __syncthreads();
+        const int ns = min(scratch[0], SAMPLE_CAP);
+        // rank in the sample whose value is, with margin, below the kp-th best of the full set
+        const float t = (float)kp / (float)stride;
+        const int want = (int)(t + 4.0f * sqrtf(t) + 6.0f);
+        uint32_t thr = 0;
+        if (ns > want) {
+            uint32_t pre = 0;
+            int rem = want;
+            for (int byte = 3; byte >= 0; --byte) {
+                hist[tid] = 0;
+                __syncthreads();
+                const int shift = byte * 8;
+                for (int i = tid; i < ns; i += 256) {
+                    const uint32_t v32 = sample[i];
+                    if (byte == 3 || (v32 >> (shift + 8)) == (pre >> (shift + 8))) atomicAdd(&hist[(v32 >> shift) & 0xff], 1);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int cum = 0, bin = 255;
+                    for (; bin >= 0; --bin) {
+                        if (cum + hist[bin] >= rem) break;
+                        cum += hist[bin];
+                    }
+                    scratch[1] = bin < 0 ? 0 : bin;
+                    scratch[3] = bin < 0 ? rem : rem - cum;
+                }
+                __syncthreads();
+                pre |= ((uint32_t)scratch[1] << shift);
+                rem = scratch[3];
+                __syncthreads();
+            }
+            thr = pre;
+        }
+        for (int p = 0; p < nprobe; ++p) {
+            const int64_t L = probes[(size_t)q * nprobe + p];
+            if (L < 0) continue;
+            const int64_t off = offsets[L];
+            const int len = (int)(offsets[L + 1] - off);
+            const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
+            for (int i = tid; i < len; i += 256) {
+                const float sc = strip[i];
+                if (sc == sc && f32_orderable(sc + 0.0f) >= thr) {
+                    const int slot = atomicAdd(&scratch[2], 1);
+                    if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)order[off + i]);
+                }
+            }
+        }
+        __syncthreads();
+        const int nc = scratch[2];
+        __syncthreads();
+        if (nc >= kp && nc <= COLLECT_CAP) {
+            for (int i = tid; i < nc; i += 256) {
+                const uint64_t ki = coll[i];
+                int rank = 0;
+                for (int j = 0; j < nc; ++j) rank += coll[j] > ki ? 1 : 0;
+                if (rank < kp) top[rank] = ki;
+            }
+            if (tid == 0) scratch[2] = kp;
+            done = true;
+        }
+        __syncthreads();
+    }
+
     uint64_t prefix = 0;
     int remaining = kp;
     const bool all = total <= kp;
-    for (int byte = 7; byte >= 0 && !all; --byte) {
+    for (int byte = 7; byte >= 0 && !all && !done; --byte) {
         hist[tid] = 0;
         __syncthreads();
         const int shift = byte * 8;
@@ -426,9 +513,9 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         __syncthreads();
     }
     const uint64_t T = all ? 0ull : prefix;
-    if (tid == 0) scratch[2] = 0;
+    if (tid == 0 && !done) scratch[2] = 0;
     __syncthreads();
-    for (int p = 0; p < nprobe; ++p) {
+    for (int p = 0; p < nprobe && !done; ++p) {
         const int64_t L = probes[(size_t)q * nprobe + p];
         if (L < 0) continue;
         const int64_t off = offsets[L];
