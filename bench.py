@@ -85,6 +85,34 @@ def committed_traffic(rows: int, b: int) -> "float | None":
     return float(t["hbm_bytes_per_launch"])
 
 
+def cpu_baseline_hnsw(rows: int, b: int, k: int) -> dict:
+    """What the reference's index actually is: HNSW m = 64, ef_construction = 500, cosine (main.py:272-276),
+    here the CPU restatement oracle/hnsw.cpp on the host cores, built over a bounded sample of the
+    synthetic DB (an HNSW over 10M x 1024 takes hours to build) and searched with the k-NN plugin's
+    default ef_search = 100.  Not scaled to N = 10M: HNSW search cost grows ~log N, recall falls with N."""
+    from oracle import retrieval as R
+    from oracle.hnsw import HnswIndex
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((rows, D), dtype=np.float32)
+    q = rng.standard_normal((b, D), dtype=np.float32)
+    q[: b // 2] = x[rng.integers(0, rows, b // 2)] + 0.1 * q[: b // 2]       # planted neighbours, as in the GPU run
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    h = HnswIndex(x, m=64, ef_construction=500, seed=0, threads=cores)
+    build_s = time.perf_counter() - t0
+    h.search(q[:64], k, ef_search=100, threads=cores)
+    t0 = time.perf_counter()
+    _, ids = h.search(q, k, ef_search=100, threads=cores)
+    dt = time.perf_counter() - t0
+    nq = min(128, b)
+    _, exact = R.exact_topk(h.xn, R.normalize_rows(q[:nq]), k)
+    recall = float(np.mean([len(set(a.tolist()) & set(e.tolist())) / k for a, e in zip(ids[:nq], exact)]))
+    return {"value": round(b / dt, 1), "unit": "queries/s", "cores": int(cores), "kind": "port",
+            "sample": f"HNSW m=64 ef_construction=500 ef_search=100 over {rows} x {D} rows (not scaled to the full index), "
+                      f"{b} queries in {dt:.3f}s, build {build_s:.1f}s",
+            "recall_at_10": round(recall, 4), "build_s": round(build_s, 2)}
+
+
 def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
     """NumPy oracle timed on the host cores, on a bounded sample of the same workload:
     fp32 normalise + Q @ X.T (OpenBLAS) + argpartition top-k over `sample_rows` rows,
@@ -157,6 +185,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--cpu-hnsw-rows", type=int, default=100_000, help="rows of the CPU HNSW baseline (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference timing")
     args = ap.parse_args()
@@ -303,6 +332,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, b, n_total, k)
+            if args.cpu_hnsw_rows > 0:
+                out["cpu_baseline_hnsw"] = cpu_baseline_hnsw(args.cpu_hnsw_rows, b, k)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

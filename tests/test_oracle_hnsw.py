@@ -1,0 +1,58 @@
+"""The CPU HNSW baseline (oracle/hnsw.cpp; parameters of the reference's index mapping, main.py:272-276)
+against the exact oracle: what recall the reference's index has, and that the implementation is sane.
+CPU only, small sizes."""
+import numpy as np
+
+from oracle import retrieval as R
+from oracle.hnsw import HnswIndex
+
+
+def _recall(ids, exact):
+    return float(np.mean([len(set(a.tolist()) & set(b.tolist())) / exact.shape[1] for a, b in zip(ids, exact)]))
+
+
+def test_clustered_data_recall_and_planted_neighbours():
+    rng = np.random.default_rng(0)
+    d, n = 128, 6000
+    centres = rng.standard_normal((32, d)).astype(np.float32)
+    x = (centres[rng.integers(0, 32, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (centres[rng.integers(0, 32, 64)] + 0.3 * rng.standard_normal((64, d))).astype(np.float32)
+    q[:8] = x[100:108] * 3.0                                # exact matches up to scale: cosine 1
+    h = HnswIndex(x, m=64, ef_construction=500, seed=0, threads=4)
+    cos, ids = h.search(q, 10, ef_search=100, threads=4)
+    ec, ei = R.exact_topk(R.normalize_rows(x), R.normalize_rows(q), 10)
+    assert _recall(ids, ei) >= 0.99
+    assert ids[:8, 0].tolist() == list(range(100, 108))
+    assert np.allclose(cos[:8, 0], 1.0, atol=1e-5)
+    assert np.all(np.diff(cos, axis=1) <= 1e-7)             # best first
+    # scores are true cosines of the returned rows
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    assert np.allclose(cos, np.take_along_axis(qn @ xn.T, ids, 1), atol=1e-5)
+
+
+def test_gaussian_data_recall_grows_with_ef():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((4000, 64)).astype(np.float32)
+    q = rng.standard_normal((50, 64)).astype(np.float32)
+    h = HnswIndex(x, seed=1, threads=4)
+    _, ei = R.exact_topk(R.normalize_rows(x), R.normalize_rows(q), 10)
+    r100 = _recall(h.search(q, 10, ef_search=100)[1], ei)
+    r800 = _recall(h.search(q, 10, ef_search=800)[1], ei)
+    assert r800 >= 0.99 and r800 >= r100 >= 0.8
+    assert h.max_level >= 1
+
+
+def test_single_thread_build_is_deterministic():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1500, 32)).astype(np.float32)
+    q = rng.standard_normal((20, 32)).astype(np.float32)
+    a = HnswIndex(x, seed=7, threads=1).search(q, 5, threads=1)
+    b = HnswIndex(x, seed=7, threads=1).search(q, 5, threads=1)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_tiny_and_empty():
+    x = np.eye(4, dtype=np.float32)
+    h = HnswIndex(x, m=4, ef_construction=8)
+    cos, ids = h.search(np.array([[0, 0, 1, 0]], np.float32), 6)
+    assert ids[0, 0] == 2 and ids[0, 4] == -1 and cos[0, 4] == -np.inf
