@@ -221,7 +221,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
 
-        if (ks == KS - 1) {
+        if (ks == KS - 1 && !(p.dbg & 4)) {                 // SQE_DBG bit 4: timing experiment, no filter
             const int64_t row0 = (int64_t)tile_of(entry) * BM;
             if (entry == 0 && !collect) {
                 filter_boot<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
