@@ -11,7 +11,9 @@ namespace sqe {
 
 namespace {
 
-constexpr int SEL_THREADS = 256;
+// Two shapes of the same kernel: small batches (many DB chunks per query, most CUs idle) give a query
+// 16 waves -- the fp32 re-score runs 16 rows at a time -- and 128 KiB of LDS for its keys; large batches
+// (64 chunks) get 4 waves and 32 KiB so that several queries share a CU.
 
 struct SelectKernelArgs {
     const uint64_t* cand;
@@ -29,24 +31,22 @@ struct SelectKernelArgs {
     float* collect_thr;
 };
 
-// MSB-first byte-wise radix select of the `kth` largest key among the valid candidates of
-// query q.  Returns 0 when there are fewer than kth candidates (everything qualifies).
-__device__ uint64_t block_select_kth(const SelectKernelArgs& p, int q, int kth, int* hist, int* scratch) {
+// MSB-first byte-wise radix select of the `kth` largest of n keys.  `get(e)` returns key e (0 = no key).
+// Returns 0 when there are fewer than kth keys (everything qualifies).
+template <int SEL_THREADS, typename Get>
+__device__ uint64_t block_select_kth(Get get, int n, int kth, int* hist, int* scratch) {
     const int tid = threadIdx.x;
-    const int total_slots = p.n_chunks * p.kp;
     uint64_t prefix = 0;      // determined high bytes
     int remaining = kth;
     for (int byte = 7; byte >= 0; --byte) {
-        hist[tid] = 0;        // SEL_THREADS == 256 bins
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = byte * 8;
-        for (int e = tid; e < total_slots; e += SEL_THREADS) {
-            const int chunk = e / p.kp, slot = e - chunk * p.kp;
-            if (slot < p.cand_cnt[(size_t)chunk * p.b_pad + q]) {
-                const uint64_t key = p.cand[((size_t)chunk * p.b_pad + q) * CAND_CAP + slot];
-                const bool match = (byte == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
-            }
+        for (int e = tid; e < n; e += SEL_THREADS) {
+            const uint64_t key = get(e);
+            if (key == 0ull) continue;
+            const bool match = (byte == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
         }
         __syncthreads();
         if (tid == 0) {
@@ -68,7 +68,9 @@ __device__ uint64_t block_select_kth(const SelectKernelArgs& p, int q, int kth, 
     return prefix;
 }
 
+template <int SEL_THREADS, int SEL_KEYS_CAP>
 __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKernelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];      // [SEL_KEYS_CAP]
     __shared__ int hist[256];
     __shared__ int scratch[4];
     __shared__ uint32_t sel_row[MAX_KP];
@@ -78,20 +80,45 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    constexpr int NW = SEL_THREADS / 64;
 
-    const uint64_t T = block_select_kth(p, q, p.kp, hist, scratch);
-
-    if (tid == 0) scratch[2] = 0;
+    // ---- gather the valid keys of this query's per-chunk lists into LDS: one wave per chunk, positions
+    // by ballot (one LDS atomic per wave and 64 slots)
+    if (tid == 0) { scratch[2] = 0; scratch[3] = 0; }
     __syncthreads();
+    for (int c = wave; c < p.n_chunks; c += NW) {
+        const int cnt = min(p.cand_cnt[(size_t)c * p.b_pad + q], p.kp);
+        const uint64_t* list = p.cand + ((size_t)c * p.b_pad + q) * CAND_CAP;
+        for (int s0 = 0; s0 < cnt; s0 += 64) {
+            const bool have = s0 + lane < cnt;
+            const uint64_t key = have ? list[s0 + lane] : 0ull;
+            const uint64_t m = __ballot(have);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&scratch[3], __popcll(m));
+            base = __shfl(base, 0, 64);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (have && pos < SEL_KEYS_CAP) keys[pos] = key;
+        }
+    }
+    __syncthreads();
+    const int n_keys = scratch[3];
+    const bool in_lds = n_keys <= SEL_KEYS_CAP;
     const int total_slots = p.n_chunks * p.kp;
-    for (int e = tid; e < total_slots; e += SEL_THREADS) {
+    auto global_key = [&](int e) -> uint64_t {
         const int chunk = e / p.kp, slot = e - chunk * p.kp;
-        if (slot < p.cand_cnt[(size_t)chunk * p.b_pad + q]) {
-            const uint64_t key = p.cand[((size_t)chunk * p.b_pad + q) * CAND_CAP + slot];
-            if (key >= T) {
-                const int pos = atomicAdd(&scratch[2], 1);
-                if (pos < MAX_KP) sel_row[pos] = key_row(key);
-            }
+        return slot < p.cand_cnt[(size_t)chunk * p.b_pad + q] ? p.cand[((size_t)chunk * p.b_pad + q) * CAND_CAP + slot] : 0ull;
+    };
+    auto lds_key = [&](int e) -> uint64_t { return keys[e]; };
+
+    const uint64_t T = in_lds ? block_select_kth<SEL_THREADS>(lds_key, n_keys, p.kp, hist, scratch)
+                              : block_select_kth<SEL_THREADS>(global_key, total_slots, p.kp, hist, scratch);
+    __syncthreads();
+    const int n_scan = in_lds ? n_keys : total_slots;
+    for (int e = tid; e < n_scan; e += SEL_THREADS) {
+        const uint64_t key = in_lds ? keys[e] : global_key(e);
+        if (key != 0ull && key >= T) {
+            const int pos = atomicAdd(&scratch[2], 1);
+            if (pos < MAX_KP) sel_row[pos] = key_row(key);
         }
     }
     __syncthreads();
@@ -101,7 +128,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
     // fp32 re-score: one wave per candidate, float4 per lane per step
     const float4* qv = reinterpret_cast<const float4*>(p.qn + (size_t)q * p.K);
     const int nvec = p.K >> 2;
-    for (int i = wave; i < m; i += SEL_THREADS / 64) {
+    for (int i = wave; i < m; i += NW) {
         const float4* rv = reinterpret_cast<const float4*>(p.master + (size_t)sel_row[i] * p.K);
         float s = 0.f;
         for (int v = lane; v < nvec; v += 64) {
@@ -216,7 +243,18 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
     k.master = a.master; k.qn = a.qn; k.K = a.K; k.B = a.B; k.k = a.k;
     k.cos_out = a.cos_out; k.id_out = a.id_out; k.id_base = a.id_base;
     k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max; k.unc_count = a.unc_count; k.collect_thr = a.collect_thr;
-    hipLaunchKernelGGL(select_rescore_kernel, dim3(a.B), dim3(SEL_THREADS), 0, stream, k);
+    if ((int64_t)a.n_chunks * a.kp > 4096) {              // few query blocks, many chunks: B <= 256
+        constexpr int LDS = 16384 * 8;
+        static bool attr = false;
+        if (!attr) {
+            SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_rescore_kernel<1024, 16384>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr = true;
+        }
+        hipLaunchKernelGGL((select_rescore_kernel<1024, 16384>), dim3(a.B), dim3(1024), LDS, stream, k);
+    } else {
+        hipLaunchKernelGGL((select_rescore_kernel<256, 4096>), dim3(a.B), dim3(256), 4096 * 8, stream, k);
+    }
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
