@@ -23,7 +23,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_${tag}/*/")):
             name = r["Kernel_Name"]
             # the main scan launches only (the collect-mode instantiation <..., true> exits at once
             # when every query is certified)
-            if "scan_bf16_p" in name or ("scan_bf16_kernel" in name and "false>" in name):
+            if "scan_bf16_p" in name or ("scan_bf16_kernel" in name and "false" in name):
                 a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
         for k, (v, n) in acc.items():
             print("${tag}", k, "per_launch=%.6g" % (v / max(n, 1)), "launches=%d" % n)
