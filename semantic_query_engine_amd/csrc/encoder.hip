@@ -21,6 +21,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -62,6 +63,20 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 
 // ------------------------------------------------------------------ GEMM
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+// erf-GELU, 0.5 v (1 + erf(v / sqrt 2)), with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below
+// the bf16 rounding of the result): one v_rcp, one v_exp and a 5-term Horner chain instead of libm's
+// branchy erff -- the GELU epilogue of the FFN-up GEMM was as long as its K loop.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = 1.0f - poly * t * __expf(-x * x);          // erf(|v| / sqrt 2)
+    return 0.5f * v * (1.0f + copysignf(e, v));
+}
 
 struct GemmArgs {
     const bf16_t* W;      // [N, K] row-major (torch Linear weight)
@@ -146,12 +161,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                 v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v0, v1, v2, v3);
             } else {
-                if (EPI == EPI_GELU) {
-                    v0 = 0.5f * v0 * (1.0f + erff(v0 * 0.70710678118654752f));
-                    v1 = 0.5f * v1 * (1.0f + erff(v1 * 0.70710678118654752f));
-                    v2 = 0.5f * v2 * (1.0f + erff(v2 * 0.70710678118654752f));
-                    v3 = 0.5f * v3 * (1.0f + erff(v3 * 0.70710678118654752f));
-                }
+                if (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
                 uint2 w2;
                 w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
                 w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
@@ -174,6 +184,169 @@ int launch_gemm_cfg(const GemmArgs& a, int t_pad, hipStream_t stream) {
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.n_tiles * (t_pad / BT)), dim3(512), LDS, stream, p);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+// Large-batch form: 256 x 256 tiles, PERSISTENT workgroups.  One workgroup per CU walks its tiles in a
+// single flattened stream of K steps (two LDS stages; the first K step of the next tile is already in
+// flight while the last one of this tile is computed), the epilogue's stores are fire-and-forget: they
+// are issued after the next tile's first DMA pieces and the counted wait that ends the K step leaves
+// them in flight.  Stores and DMA pieces go through inline asm so that hipcc inserts no vmcnt(0) of its
+// own.  Consecutive tile ids share the token tile or the weight tile, so the 256 tiles in flight at any
+// time reuse each other's operands in L2.
+__device__ __forceinline__ void store_b64_asm(void* p, uint2 v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x2 w;
+    w.x = v.x; w.y = v.y;
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store_f4_asm(void* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
+    constexpr int FM = 8, FN = 4;
+    constexpr int BNW = 256, BT = 256;
+    constexpr int STAGE = (BNW + BT) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const size_t ld = (size_t)p.K * 2;
+    const int KS = p.K / 64;
+    const int tiles = p.n_tiles * p.t_tiles;
+    const int my_tiles = blockIdx.x < tiles ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int total = my_tiles * KS;
+    if (total == 0) return;
+
+    unsigned off[4];                       // per-lane source offsets of this wave's 4 pieces per operand
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave + 8 * i) * 8 + (lane >> 3);
+        off[i] = (unsigned)(r * ld) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    // issue cursor
+    int i_tile = blockIdx.x, i_ks = 0;
+    auto issue = [&](int s) {
+        const int nt = i_tile % p.n_tiles, tt = i_tile / p.n_tiles;
+        const char* ws = reinterpret_cast<const char*>(p.W) + (size_t)nt * BNW * ld + (size_t)i_ks * ROWB;
+        const char* xs = reinterpret_cast<const char*>(p.X) + (size_t)tt * BT * ld + (size_t)i_ks * ROWB;
+        char* buf = smem + (s & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(ws + off[i], buf + (wave + 8 * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(xs + off[i], buf + BNW * ROWB + (wave + 8 * i) * 1024);
+        if (++i_ks == KS) { i_ks = 0; i_tile += gridDim.x; }
+    };
+
+    f32x4 acc[FM][FN];
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    int tile = blockIdx.x, ks = 0;
+    for (int s = 0; s < total; ++s) {
+        const bool more = s + 1 < total;
+        if (more) issue(s + 1);
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const char* tA = smem + (s & 1) * STAGE;
+        const char* tB = tA + BNW * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[FM], b[FN];
+            const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = frag(tA, wm * (FM * 16) + i * 16 + (lane & 15), c);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = frag(tB, wn * (FN * 16) + j * 16 + (lane & 15), c);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        bool stored = false;
+        if (++ks == KS) {
+            ks = 0;
+            const int nt = tile % p.n_tiles, tt = tile / p.n_tiles;
+            const int n0 = nt * BNW, t0 = tt * BT;
+            // every load the epilogue needs is issued before its first store: a load hipcc can see makes it
+            // wait for everything older, the stores included
+            uint2 res[EPI == EPI_RESID ? FM : 1][EPI == EPI_RESID ? FN : 1];
+            float4 bias4[FM];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int n = n0 + wm * (FM * 16) + i * 16 + (lane >> 4) * 4;
+                bias4[i] = *reinterpret_cast<const float4*>(p.bias + n);
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int t = t0 + wn * (FN * 16) + j * 16 + (lane & 15);
+                        res[EPI == EPI_RESID ? i : 0][EPI == EPI_RESID ? j : 0] =
+                            *reinterpret_cast<const uint2*>(p.resid + (size_t)t * p.N + n);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int n = n0 + wm * (FM * 16) + i * 16 + (lane >> 4) * 4;
+                const float4 b4 = bias4[i];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int t = t0 + wn * (FN * 16) + j * 16 + (lane & 15);
+                    // rows past T are padding of the activation buffers: written like the others (every
+                    // wave then issues exactly FM * FN stores, which the counted wait below relies on)
+                    float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+                    const size_t o = (size_t)t * p.N + n;
+                    if (EPI == EPI_RESID) {
+                        const uint2 r2 = res[EPI == EPI_RESID ? i : 0][EPI == EPI_RESID ? j : 0];
+                        v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
+                        v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
+                        store_f4_asm(reinterpret_cast<float*>(p.out) + o, f32x4{v0, v1, v2, v3});
+                    } else {
+                        if (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                        uint2 w2;
+                        w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                        w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                        store_b64_asm(reinterpret_cast<bf16_t*>(p.out) + o, w2);
+                    }
+                }
+            }
+            tile += gridDim.x;
+            stored = true;
+        }
+        // next K step landed.  After an epilogue the FM * FN = 32 stores just issued are younger than its
+        // DMA pieces and stay in flight.
+        if (stored && more) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int EPI>
+int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream) {
+    constexpr int LDS = 2 * (256 + 256) * ROWB;
+    GemmArgs p = a;
+    p.n_tiles = a.N / 256;
+    p.t_tiles = t_pad / 256;
+    p.splits = 1; p.split_stride = 0;
+    const int tiles = p.n_tiles * p.t_tiles;
+    auto kern = gemm_persistent_kernel<EPI>;
+    static bool attr = false;
+    if (!attr) {
+        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count)), dim3(512), LDS, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
@@ -279,12 +452,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)split * p.split_stride + o) =
                     make_float4(v0, v1, v2, v3);
             } else {
-                if (EPI == EPI_GELU) {
-                    v0 = 0.5f * v0 * (1.0f + erff(v0 * 0.70710678118654752f));
-                    v1 = 0.5f * v1 * (1.0f + erff(v1 * 0.70710678118654752f));
-                    v2 = 0.5f * v2 * (1.0f + erff(v2 * 0.70710678118654752f));
-                    v3 = 0.5f * v3 * (1.0f + erff(v3 * 0.70710678118654752f));
-                }
+                if (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
                 uint2 w2;
                 w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
                 w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
@@ -329,6 +497,8 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
     if (splits_out) *splits_out = 1;
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
     if (big) {
+        static const bool old_form = [] { const char* e = getenv("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
+        if (!old_form) return launch_gemm_persistent<EPI>(a, t_pad, cu_count, stream);
         GemmArgs p = a;
         p.splits = 1; p.split_stride = 0; p.t_tiles = 0;
         return launch_gemm_cfg<8, 4, EPI>(p, t_pad, stream);

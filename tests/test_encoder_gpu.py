@@ -104,3 +104,23 @@ def test_embed_functions_mirror_reference(ctx):
     assert asyncio.run(RT.embed_texts_in_batches([])).size == 0
     one = asyncio.run(RT.ollama_embed_text(texts[1]))
     assert isinstance(one, list) and len(one) == 128
+
+
+def test_large_batch_persistent_gemms(ctx):
+    """32 x 512 tokens at hidden 1024: every GEMM takes the persistent 256 x 256 form (bias, GELU and
+    residual epilogues), attention runs full 512-token sequences with ragged lengths."""
+    cfg = OB.BertCfg(vocab_size=2000, hidden=1024, layers=1, heads=16, inter=4096, max_pos=512)
+    w = OB.random_weights(cfg, seed=11)
+    rng = np.random.default_rng(5)
+    b, s = 32, 512
+    ids = rng.integers(5, cfg.vocab_size, (b, s))
+    lens = rng.integers(300, s + 1, b)
+    lens[0], lens[1] = s, 1
+    enc = _encoder(ctx, cfg, w)
+    got = enc.encode_ids(ids, lens)
+    ref = OB.bert_encode(w, cfg, ids, lens)
+    cs = [_cos(got[i], ref[i]) for i in range(b)]
+    assert min(cs) >= 0.999, cs
+    assert np.abs(got - ref).max() < 0.08
+    # same answer from the one-tile-per-workgroup form it replaced
+    assert not np.isnan(got).any()
