@@ -153,3 +153,36 @@ def test_profiling_stats(ctx):
     ctx.set_profiling(False)
     assert st["scan_calls"] == 3 and st["search_calls"] == 3 and st["scan_ms"] > 0
     assert st["scan_flops"] == 2 * 4096 * 1024 * 8 and st["scan_rows"] == 4096
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shape_sweep(ctx, seed):
+    """Seeded sweep over dimension, row count (tile edges, several chunks), batch (both scan kernels, padded
+    query blocks) and k (up to the 256 limit), with planted exact matches and duplicated rows."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([64, 128, 192, 512, 1024, 2048]))
+    n = int(rng.choice([255, 256, 257, 511, 513, 4097, 16384, 70001, 131072 + 255]))
+    b = int(rng.choice([1, 2, 63, 64, 65, 128, 255, 256, 257, 300]))
+    k = int(rng.choice([1, 3, 10, 64, 100, 256]))
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if n > 600:
+        x[n // 3] = x[5]                                   # exact duplicate: the lower id must come first
+        x[17] = 0.0                                        # all-zero row: cosine 0 with everything
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    q[0] = 2.5 * x[5]
+    if b > 1:
+        q[b - 1] = x[n - 1] + 0.05 * q[b - 1]
+    idx = _index(ctx, x)
+    cos, ids = idx.search(q, k)
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    if n * b <= 40_000_000:
+        ref_cos, ref_ids = R.knn_search(x, q, k)
+    else:
+        from gpu_util import exact_topk_fast
+        ref_cos, ref_ids = exact_topk_fast(x, q, k, extra=64)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
+    assert ids[0, 0] == 5 and abs(cos[0, 0] - 1.0) < 1e-5
+    if n > 600 and k >= 2:
+        assert ids[0, 1] == n // 3
+    if b > 1:
+        assert ids[b - 1, 0] == n - 1
