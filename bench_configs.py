@@ -5,6 +5,7 @@
                    N rows; reports the encode / search latency split
     --mode ivf     config 5: IVF-flat nlist=4096 nprobe=32 on clustered data vs the flat scan at the same N
     --mode encode  encoder throughput on full-length chunks (B x 512 tokens), tokens/s and MFMA TFLOP/s
+    --mode hard    flat scan when 0 / 8 / 200 / all queries fail the exactness certificate
     --mode cache   cache scan latency (1000 x 1024) on the GPU vs the reference's Python loop (main.py:73-87)
 
 Each mode prints one JSON line.  Single GPU.
@@ -131,6 +132,31 @@ def mode_ivf(args, ctx, dev):
                       "ivf_qps": round(b / ivf_ms * 1e3), "recall_at_10_vs_flat": round(hits / (b * k), 4)}), flush=True)
 
 
+def mode_hard(args, ctx, dev):
+    """Cost of certificate failures: a tight cluster of 3000 near-identical rows inside a random index, and
+    0 / 8 / 200 / all of the 1024 queries aimed at it (those cannot be certified from bf16 scores and take the
+    compacted collect pass)."""
+    idx = build_random_index(ctx, args.rows, dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    centre = torch.randn((1, D), generator=g, device=dev)
+    cluster = centre + 3e-3 * torch.randn((3000, D), generator=g, device=dev)
+    torch.cuda.synchronize()
+    idx.add_device(cluster.data_ptr(), 3000)
+    ctx.synchronize()
+    b, k = args.batch, 10
+    cos = torch.empty((b, k), device=dev); ids = torch.empty((b, k), dtype=torch.int64, device=dev)
+    out = {"mode": "hard", "rows": args.rows + 3000, "batch": b, "cases": []}
+    for n_hard in (0, 8, 200, b):
+        q = torch.randn((b, D), generator=g, device=dev)
+        if n_hard:
+            q[:n_hard] = centre + 3e-3 * torch.randn((n_hard, D), generator=g, device=dev)
+        torch.cuda.synchronize()
+        ctx.stats_reset()
+        ms = timed(lambda: idx.search_device(q.data_ptr(), b, k, cos.data_ptr(), ids.data_ptr()), ctx.synchronize, 5)
+        out["cases"].append({"hard_queries": n_hard, "uncertified": int(ctx.stats()["uncertified"]), "ms": round(ms, 3)})
+    print(json.dumps(out), flush=True)
+
+
 def mode_cache(args, ctx, dev):
     from oracle import retrieval as R
     from semantic_query_engine_amd.retrieval import SemanticLfuCache
@@ -156,7 +182,7 @@ def mode_cache(args, ctx, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", required=True, choices=["e2e", "ivf", "encode", "cache"])
+    ap.add_argument("--mode", required=True, choices=["e2e", "ivf", "encode", "cache", "hard"])
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=1024)
     args = ap.parse_args()
@@ -164,7 +190,7 @@ def main():
     dev = torch.device("cuda", 0)
     from semantic_query_engine_amd import Context
     ctx = Context(0)
-    {"e2e": mode_e2e, "ivf": mode_ivf, "encode": mode_encode, "cache": mode_cache}[args.mode](args, ctx, dev)
+    {"e2e": mode_e2e, "ivf": mode_ivf, "encode": mode_encode, "cache": mode_cache, "hard": mode_hard}[args.mode](args, ctx, dev)
 
 
 if __name__ == "__main__":

@@ -145,7 +145,8 @@ struct sqe_index {
     DevBuf resid_max;              // u32 float bits: max over rows of || x_hat - bf16(x_hat) ||
     DevBuf q_resid;                // [B] the same per query
     DevBuf unc;                    // int count (16 B) | float collect_thr[b_pad]
-    DevBuf fb_keys, fb_cnt;        // exact-rescan collection buffers
+    DevBuf fb_keys, fb_cnt;        // exact-rescan collection buffers (by compact index)
+    DevBuf unc_ids, thr_c, qb_c;   // uncertified queries compacted into a dense batch: ids, thresholds, bf16 rows
     int certify = 1;               // run the exactness certificate + fp32 rescan fallback
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
 };
@@ -364,7 +365,7 @@ void sqe_index_destroy(sqe_index* idx) {
         if (idx->master) (void)hipFree(idx->master);
         if (idx->scan) (void)hipFree(idx->scan);
         idx->qn.release(); idx->qb.release(); idx->cand.release(); idx->cand_cnt.release(); idx->gmax.release(); idx->dbg.release(); idx->resid_max.release(); idx->q_resid.release(); idx->unc.release();
-        idx->fb_keys.release(); idx->fb_cnt.release();
+        idx->fb_keys.release(); idx->fb_cnt.release(); idx->unc_ids.release(); idx->thr_c.release(); idx->qb_c.release();
     }
     delete idx;
 }
@@ -511,6 +512,12 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         SQE_TRY(idx->unc.ensure(16 + (size_t)plan.b_pad * 4));
         SQE_TRY(idx->fb_keys.ensure((size_t)B * EXACT_CAP * 8));
         SQE_TRY(idx->fb_cnt.ensure((size_t)B * 4));
+        SQE_TRY(idx->unc_ids.ensure((size_t)B * 4));
+        SQE_TRY(idx->thr_c.ensure((size_t)(plan.b_pad + 256) * 4));
+        if ((size_t)(plan.b_pad + 256) * idx->pitch > idx->qb_c.bytes) {
+            SQE_TRY(idx->qb_c.ensure((size_t)(plan.b_pad + 256) * idx->pitch));
+            SQE_HIP(hipMemsetAsync(idx->qb_c.p, 0, idx->qb_c.bytes, c->stream));     // rows past the count read as zero
+        }
     }
     {
         StageTimer t(c->prof, c->stream, ST_PREP);
@@ -558,20 +565,28 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         s.unc_count = unc_count; s.collect_thr = collect_thr;
         SQE_TRY(launch_select_rescore(s, c->stream));
         if (certify) {
-            // second pass for the queries whose certificate failed (both kernels return at once
-            // when there are none): collect every row that can still be in the exact top-k ...
+            // second pass for the queries whose certificate failed.  They are compacted into a dense batch on
+            // the device (no host round trip): the collect scan then costs what a batch of that size costs.
+            // Both scan shapes are enqueued; each returns at once unless the count is in its range
+            // (1..64: the HBM-bound 64-query kernel, more: 256-query blocks), and at once when it is 0.
+            const int thr_cap = plan.b_pad + 256;
+            SQE_TRY(launch_compact_uncertified(collect_thr, B, idx->qb.as<bf16_t>(), idx->pitch, K * 2, idx->unc_ids.as<int>(),
+                                               idx->thr_c.as<float>(), thr_cap, idx->qb_c.as<bf16_t>(), unc_count, c->stream));
             ScanArgs a;
-            a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
+            a.db = idx->scan; a.q = idx->qb_c.as<bf16_t>(); a.n_rows = idx->n; a.K = K; a.B = B;
             a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
             a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
             a.dbg_counters = nullptr;
-            a.collect_thr = collect_thr; a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
+            a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
             a.unc_count = unc_count;
-            SQE_TRY(launch_scan_collect(plan, a, c->stream));
+            const ScanPlan small = make_scan_plan(idx->n, 64, kp, c->cu_count);
+            SQE_TRY(launch_scan_collect(small, a, c->stream));
+            if (B > 64) SQE_TRY(launch_scan_collect(plan, a, c->stream));
             // ... and re-score them in fp32
             ExactArgs e;
             e.master = idx->master; e.qn = idx->qn.as<float>(); e.K = K; e.B = B; e.k = k;
             e.collect_thr = collect_thr; e.keys = idx->fb_keys.as<uint64_t>(); e.key_cnt = idx->fb_cnt.as<int>();
+            e.unc_ids = idx->unc_ids.as<int>(); e.unc_count = unc_count;
             e.cos_out = cos_out_dev; e.id_out = id_out_dev; e.id_base = idx->id_base;
             SQE_TRY(launch_collect_rescore(e, c->stream));
             c->last_unc_count = unc_count;

@@ -102,13 +102,19 @@ struct ExactArgs {
     const float* qn;       // [B, K] normalised queries
     int K, B, k;
     const float* collect_thr;   // [B]
-    uint64_t* keys;        // [B, EXACT_CAP]
-    const int* key_cnt;    // [B]
+    const int* unc_ids;    // [count] compact index -> query (launch_compact_uncertified)
+    const int* unc_count;  // device: number of uncertified queries
+    uint64_t* keys;        // [count, EXACT_CAP], by compact index
+    const int* key_cnt;    // [count]
     float* cos_out;
     int64_t* id_out;
     int64_t id_base;
 };
 int launch_collect_rescore(const ExactArgs& args, hipStream_t stream);
+// uncertified queries (collect_thr != +inf) -> dense batch: ids, thresholds (padded with +inf to thr_cap),
+// bf16 rows; *unc_count = their number.  Query order is kept.
+int launch_compact_uncertified(const float* collect_thr, int B, const bf16_t* qb, int pitch_bytes, int row_bytes, int* unc_ids,
+                               float* thr_out, int thr_cap, bf16_t* qb_out, int* unc_count, hipStream_t stream);
 
 // merge of [P,B,k] partial results (multi-GPU all-gather output)
 int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,

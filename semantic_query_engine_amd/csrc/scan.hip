@@ -104,6 +104,15 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
     const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
     const int q0 = qb * BN;
+    // COLLECT mode: the batch is the compacted list of uncertified queries, whose length only the device
+    // knows.  Both plans are always enqueued; the one that does not fit the count, and query blocks
+    // past it, return at once.
+    int batch = p.B;
+    if (COLLECT) {
+        batch = *p.unc_count;
+        if (batch <= 0 || q0 >= batch) return;
+        if ((p.collect_sel == 1) != (batch <= 64)) return;
+    }
 
     const int tile_begin = chunk * p.tiles_per_chunk;
     const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
@@ -122,17 +131,16 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     f.cmax = reinterpret_cast<uint32_t*>(smem + OFF_F + FL::OFF_CMAX);
     f.flags = reinterpret_cast<int*>(smem + OFF_F + FL::OFF_FLAGS);
     f.n_rows = p.n_rows;
-    f.q_live = min(BN, p.B - q0);
+    f.q_live = min(BN, batch - q0);
     f.trig = p.trig;
     f.per_wave = PER_WAVE;
     f.dbg_no_slow = (p.dbg & 16) != 0;
     f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
     constexpr bool collect = COLLECT;                    // second pass for uncertified queries
-    if (collect && *p.unc_count == 0) return;           // nothing failed its certificate
     f.collect_keys = collect ? p.collect_keys + (size_t)q0 * EXACT_CAP : nullptr;
     f.collect_cnt = collect ? p.collect_cnt + q0 : nullptr;
     for (int i = tid; i < BN; i += THREADS) {
-        const bool live = (q0 + i) < p.B;
+        const bool live = (q0 + i) < batch;
         float ts = live ? -INFINITY : INFINITY;
         uint64_t tk = live ? 0ull : ~0ull;
         if (collect && live) {
@@ -278,6 +286,7 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool
     if (collect) {
         k.collect_thr = a.collect_thr; k.collect_keys = a.collect_keys; k.collect_cnt = a.collect_cnt;
         k.unc_count = a.unc_count;
+        k.collect_sel = BN == 64 ? 1 : 2;
     }
     auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true, NST> : scan_bf16_kernel<WM, WN, FM, FN, false, NST>;
     static bool attr_set[2] = {false, false};
@@ -309,6 +318,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     }
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax; k.dbg_counters = a.dbg_counters;
     k.collect_thr = nullptr; k.collect_keys = nullptr; k.collect_cnt = nullptr; k.unc_count = nullptr;
+    k.collect_sel = 0;
     return k;
 }
 

@@ -60,7 +60,9 @@ struct ScanKernelArgs {
     const float* collect_thr;    // [b_pad] or null (normal mode); +inf = query not collected
     uint64_t* collect_keys;      // [B][EXACT_CAP]
     int* collect_cnt;            // [B]
-    const int* unc_count;        // the pass exits at once when this is 0
+    const int* unc_count;        // number of collected (uncertified) queries: the batch size of this pass, on the device
+    int collect_sel;             // which launch this is: 1 = the 64-query plan (runs when 1 <= count <= 64),
+                                 //                        2 = the 256-query plan (runs when count > 64)
 };
 
 // LDS block of the filter state for a query block of BN queries (after the staging area).

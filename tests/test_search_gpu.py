@@ -186,3 +186,31 @@ def test_random_shape_sweep(ctx, seed):
         assert ids[0, 1] == n // 3
     if b > 1:
         assert ids[b - 1, 0] == n - 1
+
+
+@pytest.mark.parametrize("n_hard,b", [(7, 200), (150, 200), (40, 40)])
+def test_partial_certificate_failures(ctx, n_hard, b):
+    """A tight cluster of near-identical rows (differences below bf16 resolution) next to random rows:
+    queries aimed at the cluster cannot be certified from bf16 scores and go through the compacted collect
+    pass (the 64-query kernel for a handful of failures, 256-query blocks beyond that); the others are
+    certified.  Every result must equal the float64 oracle."""
+    rng = np.random.default_rng(77 + n_hard)
+    d, n = 256, 30000
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    cluster_rows = rng.choice(n, 3000, replace=False)
+    x[cluster_rows] = centre + 3e-3 * rng.standard_normal((3000, d)).astype(np.float32)
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    hard = rng.choice(b, n_hard, replace=False)
+    q[hard] = centre + 3e-3 * rng.standard_normal((n_hard, d)).astype(np.float32)
+    idx = _index(ctx, x)
+    ctx.stats_reset()
+    cos, ids = idx.search(q, 10)
+    unc = ctx.stats()["uncertified"]
+    assert unc >= n_hard                                  # every hard query failed its certificate ...
+    assert unc <= n_hard + 3                              # ... and (almost) only those
+    ref_cos, ref_ids = R.knn_search(x, q, 10)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    # the hard queries' neighbours all come from the cluster, which the bf16 scan alone cannot order
+    cl = set(cluster_rows.tolist())
+    assert all(set(ids[h].tolist()) <= cl for h in hard)
