@@ -579,9 +579,15 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
             a.dbg_counters = nullptr;
             a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
             a.unc_count = unc_count;
-            const ScanPlan small = make_scan_plan(idx->n, 64, kp, c->cu_count);
-            SQE_TRY(launch_scan_collect(small, a, c->stream));
-            if (B > 64) SQE_TRY(launch_scan_collect(plan, a, c->stream));
+            // one plan per range of counts, each sized like a search of that batch (all CUs busy in every case)
+            const int bounds[5] = {0, 64, 256, 512, 1 << 30};
+            for (int r = 0; r < 4 && bounds[r] < B; ++r) {
+                const int hi = std::min(bounds[r + 1], B);
+                const ScanPlan cp = make_scan_plan(idx->n, hi, kp, c->cu_count);
+                a.collect_lo = bounds[r] + 1;
+                a.collect_hi = r == 3 ? (1 << 30) : bounds[r + 1];
+                SQE_TRY(launch_scan_collect(cp, a, c->stream));
+            }
             // ... and re-score them in fp32
             ExactArgs e;
             e.master = idx->master; e.qn = idx->qn.as<float>(); e.K = K; e.B = B; e.k = k;

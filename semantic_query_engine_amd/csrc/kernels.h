@@ -59,6 +59,7 @@ struct ScanArgs {
     uint64_t* collect_keys;
     int* collect_cnt;
     const int* unc_count;
+    int collect_lo, collect_hi;   // collect pass: this launch runs when collect_lo <= *unc_count <= collect_hi
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // pipelined form for 256-query blocks (scan8.hip); launch_scan_bf16 dispatches to it unless

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     if (COLLECT) {
         batch = *p.unc_count;
         if (batch <= 0 || q0 >= batch) return;
-        if ((p.collect_sel == 1) != (batch <= 64)) return;
+        if (batch < p.collect_lo || batch > p.collect_hi) return;
     }
 
     const int tile_begin = chunk * p.tiles_per_chunk;
@@ -286,7 +286,7 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool
     if (collect) {
         k.collect_thr = a.collect_thr; k.collect_keys = a.collect_keys; k.collect_cnt = a.collect_cnt;
         k.unc_count = a.unc_count;
-        k.collect_sel = BN == 64 ? 1 : 2;
+        k.collect_lo = a.collect_lo; k.collect_hi = a.collect_hi;
     }
     auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true, NST> : scan_bf16_kernel<WM, WN, FM, FN, false, NST>;
     static bool attr_set[2] = {false, false};
@@ -318,7 +318,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     }
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax; k.dbg_counters = a.dbg_counters;
     k.collect_thr = nullptr; k.collect_keys = nullptr; k.collect_cnt = nullptr; k.unc_count = nullptr;
-    k.collect_sel = 0;
+    k.collect_lo = 0; k.collect_hi = 0;
     return k;
 }
 

@@ -61,8 +61,7 @@ struct ScanKernelArgs {
     uint64_t* collect_keys;      // [B][EXACT_CAP]
     int* collect_cnt;            // [B]
     const int* unc_count;        // number of collected (uncertified) queries: the batch size of this pass, on the device
-    int collect_sel;             // which launch this is: 1 = the 64-query plan (runs when 1 <= count <= 64),
-                                 //                        2 = the 256-query plan (runs when count > 64)
+    int collect_lo, collect_hi;  // this launch runs when collect_lo <= count <= collect_hi (one plan per range of counts)
 };
 
 // LDS block of the filter state for a query block of BN queries (after the staging area).
