@@ -1,0 +1,42 @@
+"""The two non-default schedules of the 256-query scan kernel (scan8.hip, scan_pp.hip) stay parity-green:
+each is selected through SQE_SCAN in a child process (the choice is read once per process) and must
+return the oracle's answer on a multi-chunk index.  GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import retrieval as R
+from semantic_query_engine_amd import Context, VectorIndex
+from tests.gpu_util import assert_topk_matches, exact_topk_fast
+rng = np.random.default_rng(4)
+n, d, b, k = 300000, 256, 300, 10
+x = rng.standard_normal((n, d)).astype(np.float32)
+q = rng.standard_normal((b, d)).astype(np.float32)
+q[:50] = x[rng.integers(0, n, 50)] + 0.1 * q[:50]
+ctx = Context(0)
+idx = VectorIndex(ctx, d)
+idx.add(x)
+cos, ids = idx.search(q, k)
+ref_cos, ref_ids = exact_topk_fast(x, q, k, extra=64)
+assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+print(json.dumps({"ok": True, "uncertified": int(ctx.stats()["uncertified"])}))
+"""
+
+
+@pytest.mark.parametrize("which", ["pp", "p8"])
+def test_alternative_scan_kernels(which):
+    env = dict(os.environ, SQE_SCAN=which)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
