@@ -56,6 +56,22 @@ __device__ __forceinline__ void stage_rows(const char* gbase, size_t ld_bytes, c
         }
     }
 }
+// same tile image, pieces issued through inline asm (invisible to hipcc's waitcnt insertion: the caller
+// counts its own waits and may keep a tile in flight across LDS reads)
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_rows_asm(const char* gbase, size_t ld_bytes, char* lds, int wave, int lane) {
+    constexpr int NINSTR = ROWS / 8;
+    static_assert(NINSTR % NW == 0, "every wave issues the same number of pieces");
+    const int r_local = lane >> 3;
+    const int cprime = lane & 7;
+#pragma unroll
+    for (int it = 0; it < NINSTR / NW; ++it) {
+        const int g = it * NW + wave;
+        const int r = g * 8 + r_local;
+        const int c = cprime ^ ((r >> 1) & 7);
+        lds_dma16(gbase + (size_t)r * ld_bytes + c * 16, lds + g * 1024);
+    }
+}
 __device__ __forceinline__ bf16x8 frag(const char* tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(tile + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4));
 }
@@ -615,17 +631,24 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
 
 // ------------------------------------------------------------------ attention (head_dim = 64)
 // grid = B * heads * ceil(S / 64); 256 threads = 4 waves x 16 query rows.
-__device__ __forceinline__ uint2 lds_tr_b64(const char* addr) {
-    uint2 v;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+// issue only: the caller waits once for a batch of these (lds_tr_wait8)
+__device__ __forceinline__ u32x2 lds_tr_b64_issue(const char* addr) {
+    u32x2 v;
     const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)addr;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(v) : "v"(a) : "memory");
     return v;
+}
+__device__ __forceinline__ void lds_tr_wait8(u32x2 (&x)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+                 :
+                 : "memory");
 }
 
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens,
                                                         bf16_t* __restrict__ ctx, int S, int H, int heads) {
-    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sV[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sKV[2][2 * 64 * ROWB];    // [buffer][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qblocks = (S + 63) / 64;
@@ -652,11 +675,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int dj = 0; dj < 4; ++dj) o[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kv0 = 0; kv0 < len; kv0 += 64) {
-        __syncthreads();                              // previous tile fully consumed
-        stage_rows<64, 4>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sK, wave, lane);       // K part
-        stage_rows<64, 4>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sV, wave, lane);   // V part
-        __syncthreads();                              // vmcnt(0) + barrier
+    // K/V tiles are double buffered: tile t + 1 is fetched while tile t is used (one barrier per tile)
+    auto issue_kv = [&](int kv0, int buf) {
+        stage_rows_asm<64, 4>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sKV[buf], wave, lane);                   // K part
+        stage_rows_asm<64, 4>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sKV[buf] + 64 * ROWB, wave, lane);   // V part
+    };
+    issue_kv(0, 0);
+    int buf = 0;
+    for (int kv0 = 0; kv0 < len; kv0 += 64, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // my pieces of this tile landed, my LDS reads are done
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                  // everyone's landed; everyone left the other buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (kv0 + 64 < len) issue_kv(kv0 + 64, buf ^ 1);
+        const char* sK = sKV[buf];
+        const char* sV = sKV[buf] + 64 * ROWB;
         // S^T[key][q] = sum_d K[key][d] Q[q][d]
         f32x4 st[4];
 #pragma unroll
@@ -711,22 +744,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                 const bf16_t hb = f32_to_bf16(st[2 * kk2 + (j >> 2)][j & 3]);
                 pa[j] = __builtin_bit_cast(__bf16, hb);
             }
+            // lane (g, c = 4*qq + pp) supplies row qq of each 4-key block, columns dj*16 + 4*pp ..;
+            // the eight transposed reads of this half go out together and are waited for once
+            u32x2 vt[8];
 #pragma unroll
             for (int dj = 0; dj < 4; ++dj) {
-                // lane (g, c = 4*qq + pp) supplies row qq of each 4-key block, columns dj*16 + 4*pp ..
                 const int qq = c >> 2, pp = c & 3;
                 const int chunk = dj * 2 + (pp >> 1);
-                uint2 lo, hi;
-                {
-                    const int key = 16 * (2 * kk2) + 4 * g + qq;
-                    lo = lds_tr_b64(sV + key * ROWB + ((chunk ^ ((key >> 1) & 7)) << 4) + 8 * (pp & 1));
-                }
-                {
-                    const int key = 16 * (2 * kk2 + 1) + 4 * g + qq;
-                    hi = lds_tr_b64(sV + key * ROWB + ((chunk ^ ((key >> 1) & 7)) << 4) + 8 * (pp & 1));
-                }
+                const int key_lo = 16 * (2 * kk2) + 4 * g + qq, key_hi = 16 * (2 * kk2 + 1) + 4 * g + qq;
+                vt[2 * dj] = lds_tr_b64_issue(sV + key_lo * ROWB + ((chunk ^ ((key_lo >> 1) & 7)) << 4) + 8 * (pp & 1));
+                vt[2 * dj + 1] = lds_tr_b64_issue(sV + key_hi * ROWB + ((chunk ^ ((key_hi >> 1) & 7)) << 4) + 8 * (pp & 1));
+            }
+            lds_tr_wait8(vt);
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) {
                 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-                const u32x4 packed = {lo.x, lo.y, hi.x, hi.y};
+                const u32x4 packed = {vt[2 * dj].x, vt[2 * dj].y, vt[2 * dj + 1].x, vt[2 * dj + 1].y};
                 const bf16x8 vb = __builtin_bit_cast(bf16x8, packed);
                 o[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dj], 0, 0, 0);
             }
