@@ -5,6 +5,7 @@
                    N rows; reports the encode / search latency split
     --mode ivf     config 5: IVF-flat nlist=4096 nprobe=32 on clustered data vs the flat scan at the same N
     --mode encode  encoder throughput on full-length chunks (B x 512 tokens), tokens/s and MFMA TFLOP/s
+    --mode ingest  config 1 plumbing: text chunks -> tokens -> embeddings -> index, chunks/s
     --mode hard    flat scan when 0 / 8 / 200 / all queries fail the exactness certificate
     --mode cache   cache scan latency (1000 x 1024) on the GPU vs the reference's Python loop (main.py:73-87)
 
@@ -157,6 +158,46 @@ def mode_hard(args, ctx, dev):
     print(json.dumps(out), flush=True)
 
 
+def mode_ingest(args, ctx, dev):
+    """Config 1 plumbing: text chunks of 512 words -> C++ WordPiece -> BERT-large (random bf16 weights) ->
+    normalise + index, through the reference-named bulk call (`embed_texts_in_batches`, main.py:148-169) and
+    `OpenSearchIndexer.add_embeddings` (main.py:309-338).  Synthetic text over a synthetic 8k-word vocabulary."""
+    import asyncio
+    from oracle import bert as OB
+    from semantic_query_engine_amd import retrieval as RT
+    from semantic_query_engine_amd.encoder import BertEncoder
+    from semantic_query_engine_amd.tokenizer import WordPieceTokenizer
+    cfg = OB.BertCfg()
+    enc = BertEncoder(ctx)
+    enc.load_weights({k: v.numpy() for k, v in OB.random_weights(cfg, seed=0).items()})
+    rng = np.random.default_rng(0)
+    letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+    words = sorted({"".join(rng.choice(letters, rng.integers(3, 10))) for _ in range(9000)})[:8000]
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + ["##" + w[:3] for w in words[:2000]]
+    vocab += [f"[unused{i}]" for i in range(cfg.vocab_size - len(vocab))]
+    tok = WordPieceTokenizer(vocab_text="\n".join(vocab) + "\n")
+    RT.configure_embedder(RT.Embedder(enc, tok))
+    n = args.batch if args.batch != 1024 else 2048
+    texts = [" ".join(words[j] for j in rng.integers(0, len(words), 512)) for _ in range(n)]
+    docs = [{"doc_id": f"PMC{i // 11}.txt", "text": t} for i, t in enumerate(texts)]
+    asyncio.run(RT.embed_texts_in_batches(texts[:128]))                      # warm-up
+    t0 = time.perf_counter()
+    ids, lens = tok.encode_batch(texts, 512)
+    tok_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    emb = asyncio.run(RT.embed_texts_in_batches(texts))
+    embed_s = time.perf_counter() - t0
+    ix = RT.OpenSearchIndexer(RT.GpuSearchClient(ctx, dim=D), "medical-search-index")
+    t0 = time.perf_counter()
+    ix.add_embeddings(emb, docs)
+    ctx.synchronize()
+    add_s = time.perf_counter() - t0
+    print(json.dumps({"mode": "ingest", "chunks": n, "mean_tokens": round(float(lens.mean()), 1),
+                      "tokenize_only_s": round(tok_s, 3), "embed_s": round(embed_s, 3), "index_add_s": round(add_s, 3),
+                      "chunks_per_s": round(n / (embed_s + add_s), 1),
+                      "note": "embed_s includes tokenisation (overlapped with the GPU on a worker thread)"}), flush=True)
+
+
 def mode_cache(args, ctx, dev):
     from oracle import retrieval as R
     from semantic_query_engine_amd.retrieval import SemanticLfuCache
@@ -182,7 +223,7 @@ def mode_cache(args, ctx, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", required=True, choices=["e2e", "ivf", "encode", "cache", "hard"])
+    ap.add_argument("--mode", required=True, choices=["e2e", "ivf", "encode", "cache", "hard", "ingest"])
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=1024)
     args = ap.parse_args()
@@ -190,7 +231,7 @@ def main():
     dev = torch.device("cuda", 0)
     from semantic_query_engine_amd import Context
     ctx = Context(0)
-    {"e2e": mode_e2e, "ivf": mode_ivf, "encode": mode_encode, "cache": mode_cache, "hard": mode_hard}[args.mode](args, ctx, dev)
+    {"e2e": mode_e2e, "ivf": mode_ivf, "encode": mode_encode, "cache": mode_cache, "hard": mode_hard, "ingest": mode_ingest}[args.mode](args, ctx, dev)
 
 
 if __name__ == "__main__":

@@ -297,13 +297,35 @@ class Embedder:
         self.encoder, self.tokenizer, self.max_len = encoder, tokenizer, max_len
         self._lock = threading.Lock()
 
+    def _tokenize(self, texts: List[str]):
+        ids, lens = self.tokenizer.encode_batch(texts, self.max_len)
+        s = int(min(self.max_len, max(16, (int(lens.max()) + 15) // 16 * 16)))
+        return ids[:, :s], lens
+
     def embed(self, texts: List[str]) -> np.ndarray:
         if not texts:
             return np.zeros((0, self.encoder.cfg["hidden"]), np.float32)
-        ids, lens = self.tokenizer.encode_batch(texts, self.max_len)
-        s = int(min(self.max_len, max(16, (int(lens.max()) + 15) // 16 * 16)))
+        ids, lens = self._tokenize(texts)
         with self._lock:
-            return self.encoder.encode_ids(ids[:, :s], lens)
+            return self.encoder.encode_ids(ids, lens)
+
+    def embed_batches(self, texts: List[str], batch_size: int = 64) -> np.ndarray:
+        """Order-preserving bulk form: the WordPiece tokenisation of batch i + 1 (host, GIL released inside
+        the C++ tokenizer) runs on a worker thread while the GPU encodes batch i."""
+        if not texts:
+            return np.zeros((0, self.encoder.cfg["hidden"]), np.float32)
+        from concurrent.futures import ThreadPoolExecutor
+        chunks = [texts[i:i + batch_size] for i in range(0, len(texts), batch_size)]
+        out = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(self._tokenize, chunks[0])
+            for i in range(len(chunks)):
+                ids, lens = nxt.result()
+                if i + 1 < len(chunks):
+                    nxt = pool.submit(self._tokenize, chunks[i + 1])
+                with self._lock:
+                    out.append(self.encoder.encode_ids(ids, lens))
+        return np.concatenate(out, axis=0)
 
 
 _embedder: Optional[Embedder] = None
@@ -330,9 +352,7 @@ async def embed_texts_in_batches(texts: List[str], batch_size: int = 64) -> np.n
     """main.py:148-169: order-preserving embedding of ``texts`` -> float32 [n, 1024]; [] -> np.array([])."""
     if not texts:
         return np.array([])
-    emb = _require_embedder()
-    out = [emb.embed(texts[i:i + batch_size]) for i in range(0, len(texts), batch_size)]
-    return np.concatenate(out, axis=0).astype(np.float32)
+    return _require_embedder().embed_batches(texts, batch_size).astype(np.float32)
 
 
 async def embed_query(query: str) -> np.ndarray:
