@@ -78,7 +78,7 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int r, int c) {
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
 
 // ------------------------------------------------------------------ GEMM
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_F32 = 3 };   // EPI_F32: plain fp32 products, no bias (IVF coarse scores)
 
 // erf-GELU, 0.5 v (1 + erf(v / sqrt 2)), with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below
 // the bf16 rounding of the result): one v_rcp, one v_exp and a 5-term Horner chain instead of libm's
@@ -451,15 +451,17 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int n = n0 + wm * (FM * 16) + i * 16 + (lane >> 4) * 4;
-        float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-        if (EPI == EPI_RESID && split != 0) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI != EPI_F32 && !(EPI == EPI_RESID && split != 0)) b4 = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int t = t0 + wn * (FN * 16) + j * 16 + (lane & 15);
             if (t >= p.T) continue;
             float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
             const size_t o = (size_t)t * p.N + n;
-            if (EPI == EPI_RESID) {
+            if (EPI == EPI_F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v0, v1, v2, v3);
+            } else if (EPI == EPI_RESID) {
                 if (split == 0) {
                     const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o);
                     v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
@@ -520,6 +522,13 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
         return launch_gemm_cfg<8, 4, EPI>(p, t_pad, stream);
     }
     return launch_gemm_ring<EPI>(a, t_pad, cu_count, split_stride, splits_out, stream);
+}
+
+// scores[t][n] = <X[t], W[n]> in fp32 (bf16 operands, rows K elements apart): the IVF coarse quantiser
+int scores_gemm(const bf16_t* W, const bf16_t* X, float* out, int N, int K, int T, int t_pad, int cu_count, hipStream_t stream) {
+    GemmArgs a;
+    a.W = W; a.X = X; a.bias = nullptr; a.resid = nullptr; a.out = out; a.N = N; a.K = K; a.T = T; a.n_tiles = 0;
+    return launch_gemm_ring<EPI_F32>(a, t_pad, cu_count, 0, nullptr, stream);
 }
 
 // ------------------------------------------------------------------ LayerNorm family
@@ -804,6 +813,11 @@ bf16_t host_bf16(float f) {
 }
 
 }  // namespace
+
+int launch_scores_gemm(const bf16_t* W, const bf16_t* X, float* out, int N, int K, int T, int t_pad, int cu_count, hipStream_t stream) {
+    if (N % 128 != 0 || K % 64 != 0 || t_pad % 128 != 0 || T > t_pad) return fail(SQE_ERR_INVALID, "scores gemm: N % 128, K % 64, t_pad % 128");
+    return scores_gemm(W, X, out, N, K, T, t_pad, cu_count, stream);
+}
 }  // namespace sqe
 
 using namespace sqe;

@@ -131,6 +131,69 @@ __global__ void ivf_scatter_kernel(const int* __restrict__ assign, int64_t n, co
     order[offsets[a] + atomicAdd(cursor + a, 1)] = (int)i;
 }
 
+// top-nprobe lists of a query from its dense coarse scores [nlist] (score desc, list id asc); one workgroup
+// per query, scores staged in LDS, byte-wise radix select on (orderable score, ~id) keys
+__global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __restrict__ scores, int nlist, int nprobe,
+                                                               int64_t* __restrict__ probes, float* __restrict__ probes_cos) {
+    extern __shared__ __attribute__((aligned(16))) float ssc[];      // [nlist]
+    __shared__ int hist[256];
+    __shared__ int scratch[4];
+    __shared__ uint64_t top[MAX_KP];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < nlist; i += 256) ssc[i] = scores[(size_t)q * nlist + i];
+    __syncthreads();
+    auto key_of = [&](int i) { return make_key(ssc[i] + 0.0f, (uint32_t)i); };
+    uint64_t prefix = 0;
+    int remaining = nprobe;
+    const bool all = nlist <= nprobe;
+    for (int byte = 7; byte >= 0 && !all; --byte) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int shift = byte * 8;
+        for (int i = tid; i < nlist; i += 256) {
+            const uint64_t key = key_of(i);
+            if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, bin = 255;
+            for (; bin >= 0; --bin) {
+                if (cum + hist[bin] >= remaining) break;
+                cum += hist[bin];
+            }
+            scratch[0] = bin < 0 ? 0 : bin;
+            scratch[1] = bin < 0 ? remaining : remaining - cum;
+        }
+        __syncthreads();
+        prefix |= ((uint64_t)scratch[0] << shift);
+        remaining = scratch[1];
+        __syncthreads();
+    }
+    const uint64_t T = all ? 0ull : prefix;
+    if (tid == 0) scratch[2] = 0;
+    __syncthreads();
+    for (int i = tid; i < nlist; i += 256) {
+        const uint64_t key = key_of(i);
+        if (key >= T) {
+            const int slot = atomicAdd(&scratch[2], 1);
+            if (slot < MAX_KP) top[slot] = key;
+        }
+    }
+    __syncthreads();
+    const int m = min(scratch[2], nprobe);
+    for (int i = tid; i < m; i += 256) {
+        const uint64_t ki = top[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += top[j] > ki ? 1 : 0;
+        probes[(size_t)q * nprobe + rank] = (int64_t)key_row(ki);
+        probes_cos[(size_t)q * nprobe + rank] = key_score(ki);
+    }
+    for (int i = m + tid; i < nprobe; i += 256) {
+        probes[(size_t)q * nprobe + i] = -1;
+        probes_cos[(size_t)q * nprobe + i] = -INFINITY;
+    }
+}
+
 // (query, probe) pairs bucketed by list
 __global__ void ivf_bucket_kernel(const int64_t* __restrict__ probes, int B, int nprobe, int* __restrict__ lcount,
                                   int* __restrict__ lq, int cap) {
@@ -578,10 +641,11 @@ struct IvfState {
     sqe_index* coarse = nullptr;       // flat index over the centroids
     bool trained = false;
     bool lists_dirty = true;
+    bool cent_dirty = true;            // dense bf16 copy of the centroids (coarse GEMM) is stale
     int64_t n_assigned = 0;            // rows of the base index that have an assignment
     int max_len = 0;
     Buf centroids, assign, order, offsets, counts, cursor;   // device
-    Buf qn, qb, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
+    Buf qn, qb, qd, cent_bf16, cscores, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
 };
 
@@ -713,6 +777,7 @@ int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int 
     SQE_TRY(sqe_index_add_device(st->coarse, st->centroids.as<float>(), nlist));
     SQE_HIP(hipStreamSynchronize(s));
     st->trained = true;
+    st->cent_dirty = true;
     st->n_assigned = 0;                    // (re)assign everything stored so far
     st->lists_dirty = true;
     return ivf_rows_added(base, st);
@@ -738,8 +803,34 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     SQE_TRY(st->lq.ensure((size_t)nlist * B * 4));
     SQE_TRY(st->pair_scores.ensure((size_t)B * nprobe * max_len * 4));
     SQE_TRY(launch_normalize_rows(q_dev, B, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
-    // S5: coarse quantise
-    SQE_TRY(sqe_index_search_device(st->coarse, st->qn.as<float>(), B, nprobe, 0, st->probes_cos.as<float>(), st->probes_ids.as<int64_t>()));
+    // S5: coarse quantise.  nlist is a few thousand rows: too small for the streaming scan (its chunks could
+    // not even fill the global-bound table), so the whole [B, nlist] score matrix is one small GEMM
+    // (bf16 operands, fp32 out) and a per-query select; the scan remains the path for odd nlist.
+    if (nlist % 128 == 0 && nlist <= 16384 && (size_t)nlist * 4 <= 64 * 1024) {
+        const int t_pad = (B + 127) / 128 * 128;
+        SQE_TRY(st->qd.ensure((size_t)t_pad * dim * 2));
+        SQE_TRY(st->cscores.ensure((size_t)t_pad * nlist * 4));
+        if (st->cent_dirty) {
+            SQE_TRY(st->cent_bf16.ensure((size_t)nlist * dim * 2));
+            SQE_TRY(launch_normalize_rows(index_master(st->coarse), nlist, dim, nullptr, st->cent_bf16.as<bf16_t>(), dim, nullptr, nullptr, s));
+            st->cent_dirty = false;
+        }
+        if (t_pad > B) SQE_HIP(hipMemsetAsync(st->qd.as<char>() + (size_t)B * dim * 2, 0, (size_t)(t_pad - B) * dim * 2, s));
+        SQE_TRY(launch_normalize_rows(q_dev, B, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
+        SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, B, t_pad,
+                                   ctx_cu_count(ctx), s));
+        static bool attr = false;
+        if (!attr) {
+            SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_probe_select_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(B), dim3(256), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, nprobe,
+                           st->probes_ids.as<int64_t>(), st->probes_cos.as<float>());
+        SQE_HIP(hipGetLastError());
+    } else {
+        SQE_TRY(sqe_index_search_device(st->coarse, st->qn.as<float>(), B, nprobe, 0, st->probes_cos.as<float>(), st->probes_ids.as<int64_t>()));
+    }
     SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)nlist * 4, s));
     hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
                        st->lcount.as<int>(), st->lq.as<int>(), B);
@@ -782,6 +873,7 @@ int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const
     if (n > 0) SQE_HIP(hipMemcpyAsync(st->assign.p, assign_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     SQE_HIP(hipStreamSynchronize(s));
     st->trained = true;
+    st->cent_dirty = true;
     st->n_assigned = n;
     st->lists_dirty = true;
     return SQE_OK;

@@ -117,6 +117,10 @@ int launch_collect_rescore(const ExactArgs& args, hipStream_t stream);
 int launch_compact_uncertified(const float* collect_thr, int B, const bf16_t* qb, int pitch_bytes, int row_bytes, int* unc_ids,
                                float* thr_out, int thr_cap, bf16_t* qb_out, int* unc_count, hipStream_t stream);
 
+// out[t][n] = <X[t], W[n]> fp32 from bf16 rows of K elements (dense, K * 2 bytes apart); N % 128 == 0,
+// K % 64 == 0, X holds t_pad % 128 == 0 rows.  The encoder's small-batch GEMM (encoder.hip); IVF coarse scores.
+int launch_scores_gemm(const bf16_t* W, const bf16_t* X, float* out, int N, int K, int T, int t_pad, int cu_count, hipStream_t stream);
+
 // merge of [P,B,k] partial results (multi-GPU all-gather output)
 int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,
                       int P, int B, int k, float* cos_out, int64_t* id_out, hipStream_t stream);
