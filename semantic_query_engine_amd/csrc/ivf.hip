@@ -649,6 +649,46 @@ struct IvfState {
     std::vector<int64_t> h_offsets;
 };
 
+// Top-kk lists of b rows (raw fp32, normalised here) against the centroids.  A few thousand centroids are too
+// few rows for the streaming scan (its chunks could not even fill the global-bound table), so when nlist
+// allows it the whole [b, nlist] score matrix is one small GEMM (dense bf16 copies of both sides, fp32 out,
+// the encoder's ring GEMM) followed by a per-row radix select; otherwise the flat index over the centroids.
+static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev, int64_t b, int kk, int64_t* ids_out,
+                           float* cos_out) {
+    sqe_ctx* ctx = index_ctx(base);
+    hipStream_t s = ctx_stream(ctx);
+    const int nlist = index_nlist(base), dim = index_dim(base);
+    const bool dense = nlist % 128 == 0 && (size_t)nlist * 4 <= 64 * 1024 && kk <= MAX_KP;
+    if (!dense) return sqe_index_search_device(st->coarse, rows_dev, (int)b, kk, 0, cos_out, ids_out);
+    if (st->cent_dirty) {
+        SQE_TRY(st->cent_bf16.ensure((size_t)nlist * dim * 2));
+        SQE_TRY(launch_normalize_rows(index_master(st->coarse), nlist, dim, nullptr, st->cent_bf16.as<bf16_t>(), dim, nullptr, nullptr, s));
+        st->cent_dirty = false;
+    }
+    static bool attr = false;
+    if (!attr) {
+        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_probe_select_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr = true;
+    }
+    const int64_t step = 16384;
+    const int64_t cap = std::min(step, (b + 127) / 128 * 128);
+    SQE_TRY(st->qd.ensure((size_t)cap * dim * 2));
+    SQE_TRY(st->cscores.ensure((size_t)cap * nlist * 4));
+    for (int64_t off = 0; off < b; off += step) {
+        const int m = (int)std::min(step, b - off);
+        const int t_pad = (m + 127) / 128 * 128;
+        if (t_pad > m) SQE_HIP(hipMemsetAsync(st->qd.as<char>() + (size_t)m * dim * 2, 0, (size_t)(t_pad - m) * dim * 2, s));
+        SQE_TRY(launch_normalize_rows(rows_dev + (size_t)off * dim, m, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
+        SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, m, t_pad,
+                                   ctx_cu_count(ctx), s));
+        hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(m), dim3(256), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, kk,
+                           ids_out + off * kk, cos_out + off * kk);
+        SQE_HIP(hipGetLastError());
+    }
+    return SQE_OK;
+}
+
 static int ivf_assign_rows(sqe_index* base, IvfState* st, const float* rows_dev, int64_t n, int* assign_out,
                            int64_t* ids64_out /* optional [n] */) {
     // cosine top-1 of `rows_dev` against the centroids, in batches
@@ -660,8 +700,7 @@ static int ivf_assign_rows(sqe_index* base, IvfState* st, const float* rows_dev,
     SQE_TRY(st->tmp_cos.ensure((size_t)std::min(batch, n) * 4));
     for (int64_t off = 0; off < n; off += batch) {
         const int b = (int)std::min(batch, n - off);
-        SQE_TRY(sqe_index_search_device(st->coarse, rows_dev + (size_t)off * dim, b, 1, 0, st->tmp_cos.as<float>(),
-                                        st->tmp_ids.as<int64_t>()));
+        SQE_TRY(ivf_coarse_topk(base, st, rows_dev + (size_t)off * dim, b, 1, st->tmp_ids.as<int64_t>(), st->tmp_cos.as<float>()));
         if (assign_out)
             hipLaunchKernelGGL(ivf_store_assign_kernel, dim3((b + 255) / 256), dim3(256), 0, s, st->tmp_ids.as<int64_t>(),
                                (int64_t)b, assign_out + off, (int*)nullptr);
@@ -764,6 +803,7 @@ int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int 
     for (int it = 0; it < iters; ++it) {
         index_clear(st->coarse);
         SQE_TRY(sqe_index_add_device(st->coarse, st->centroids.as<float>(), nlist));
+        st->cent_dirty = true;
         SQE_TRY(ivf_assign_rows(base, st, xs.as<float>(), n, nullptr, assign64.as<int64_t>()));
         SQE_HIP(hipMemsetAsync(st->sums.p, 0, (size_t)nlist * dim * 4, s));
         SQE_HIP(hipMemsetAsync(st->counts.p, 0, (size_t)nlist * 4, s));
@@ -803,34 +843,8 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     SQE_TRY(st->lq.ensure((size_t)nlist * B * 4));
     SQE_TRY(st->pair_scores.ensure((size_t)B * nprobe * max_len * 4));
     SQE_TRY(launch_normalize_rows(q_dev, B, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
-    // S5: coarse quantise.  nlist is a few thousand rows: too small for the streaming scan (its chunks could
-    // not even fill the global-bound table), so the whole [B, nlist] score matrix is one small GEMM
-    // (bf16 operands, fp32 out) and a per-query select; the scan remains the path for odd nlist.
-    if (nlist % 128 == 0 && nlist <= 16384 && (size_t)nlist * 4 <= 64 * 1024) {
-        const int t_pad = (B + 127) / 128 * 128;
-        SQE_TRY(st->qd.ensure((size_t)t_pad * dim * 2));
-        SQE_TRY(st->cscores.ensure((size_t)t_pad * nlist * 4));
-        if (st->cent_dirty) {
-            SQE_TRY(st->cent_bf16.ensure((size_t)nlist * dim * 2));
-            SQE_TRY(launch_normalize_rows(index_master(st->coarse), nlist, dim, nullptr, st->cent_bf16.as<bf16_t>(), dim, nullptr, nullptr, s));
-            st->cent_dirty = false;
-        }
-        if (t_pad > B) SQE_HIP(hipMemsetAsync(st->qd.as<char>() + (size_t)B * dim * 2, 0, (size_t)(t_pad - B) * dim * 2, s));
-        SQE_TRY(launch_normalize_rows(q_dev, B, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
-        SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, B, t_pad,
-                                   ctx_cu_count(ctx), s));
-        static bool attr = false;
-        if (!attr) {
-            SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_probe_select_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr = true;
-        }
-        hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(B), dim3(256), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, nprobe,
-                           st->probes_ids.as<int64_t>(), st->probes_cos.as<float>());
-        SQE_HIP(hipGetLastError());
-    } else {
-        SQE_TRY(sqe_index_search_device(st->coarse, st->qn.as<float>(), B, nprobe, 0, st->probes_cos.as<float>(), st->probes_ids.as<int64_t>()));
-    }
+    // S5: coarse quantise
+    SQE_TRY(ivf_coarse_topk(base, st, q_dev, B, nprobe, st->probes_ids.as<int64_t>(), st->probes_cos.as<float>()));
     SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)nlist * 4, s));
     hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
                        st->lcount.as<int>(), st->lq.as<int>(), B);
