@@ -259,7 +259,7 @@ __device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j) {
     P.advance(P.dm);
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool SYNCF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -361,6 +361,76 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     }
     __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
 
+    if constexpr (SYNCF) {
+        // Both groups filter a finished tile in the SAME phase (no MFMAs in it): G0, one phase ahead, first
+        // loads the operands of the next tile's first half-step and then waits for G1's last compute phase.
+        // The filter is then paid once per tile instead of once per group.
+        //     G0: .. CMP(e,last) | MEM(e+1,0) | FILTER(e) | CMP(e+1,0) | MEM(e+1,1) ..
+        //     G1: .. MEM(e,last) | CMP(e,last)| FILTER(e) | MEM(e+1,0) | CMP(e+1,0) ..
+        if (P.J > 0) {
+            const int HS = P.HS;
+            int j = 0;
+            auto filter_phase = [&](int e) {
+                if (!P.no_filter) {
+                    const int fl = fresh_lane();
+                    if (e == 0) filter_boot<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl);
+                    else filter_tile<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (group == 0) {
+                mem_phase<false, SPLIT>(P, f, acc, a, b, 0);
+                PP_BARRIER();
+                for (int e = 0; e < n_entries; ++e) {
+                    if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
+                    if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
+                    PP_BARRIER();
+                    mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                    PP_BARRIER();
+                    ++j;
+                    for (int h = 1; h < HS - 1; ++h) {
+                        if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                        PP_BARRIER();
+                        if (j + 1 < P.lean_until) mem_lean<SPLIT>(P, a, b, j + 1);
+                        else mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                        PP_BARRIER();
+                        ++j;
+                    }
+                    if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                    PP_BARRIER();
+                    if (e + 1 < n_entries) mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                    PP_BARRIER();
+                    ++j;
+                    if (e + 1 < n_entries) {
+                        filter_phase(e);
+                        PP_BARRIER();
+                    }
+                }
+            } else {
+                PP_BARRIER();
+                for (int e = 0; e < n_entries; ++e) {
+                    if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
+                    mem_phase<false, SPLIT>(P, f, acc, a, b, j);
+                    PP_BARRIER();
+                    if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
+                    PP_BARRIER();
+                    ++j;
+                    for (int h = 1; h < HS; ++h) {
+                        if (j < P.lean_until) mem_lean<SPLIT>(P, a, b, j);
+                        else mem_phase<false, SPLIT>(P, f, acc, a, b, j);
+                        PP_BARRIER();
+                        if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                        PP_BARRIER();
+                        ++j;
+                    }
+                    if (e + 1 < n_entries) {
+                        filter_phase(e);
+                        PP_BARRIER();
+                    }
+                }
+            }
+        }
+    } else
     if (P.J > 0) {
         const int HS = P.HS;
         int j = 0;                         // half-step of the compute phase
@@ -430,8 +500,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
 int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (plan.bn != BNP) return fail(SQE_ERR_INVALID, "scan pp: query block must be 256");
     ScanKernelArgs k = make_kernel_args(plan, a);
-    static const bool split = [] { const char* e = getenv("SQE_PP_SPLIT"); return !(e && e[0] == '0'); }();
-    auto kern = split ? scan_bf16_pp_kernel<true> : scan_bf16_pp_kernel<false>;
+    static const bool split = [] { const char* e = getenv("SQE_PP_SPLIT"); return e && e[0] == '1'; }();   // measured slower
+    static const bool syncf = [] { const char* e = getenv("SQE_PP_SYNCF"); return !(e && e[0] == '0'); }();
+    auto kern = syncf ? (split ? scan_bf16_pp_kernel<true, true> : scan_bf16_pp_kernel<false, true>)
+                      : (split ? scan_bf16_pp_kernel<true, false> : scan_bf16_pp_kernel<false, false>);
     static bool attr_set = false;
     if (!attr_set) {
         SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));

@@ -1,4 +1,4 @@
-"""The two non-default schedules of the 256-query scan kernel (scan8.hip, scan_pp.hip) stay parity-green:
+"""Every schedule of the 256-query scan kernel (scan.hip v0, scan8.hip p8, scan_pp.hip pp = the default) stays parity-green:
 each is selected through SQE_SCAN in a child process (the choice is read once per process) and must
 return the oracle's answer on a multi-chunk index.  GPU only."""
 import json
@@ -34,7 +34,7 @@ print(json.dumps({"ok": True, "uncertified": int(ctx.stats()["uncertified"])}))
 """
 
 
-@pytest.mark.parametrize("which", ["pp", "p8"])
+@pytest.mark.parametrize("which", ["v0", "p8", "pp"])
 def test_alternative_scan_kernels(which):
     env = dict(os.environ, SQE_SCAN=which)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
