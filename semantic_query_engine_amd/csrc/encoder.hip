@@ -655,23 +655,27 @@ __device__ __forceinline__ void lds_tr_wait8(u32x2 (&x)[8]) {
                  : "memory");
 }
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens,
-                                                        bf16_t* __restrict__ ctx, int S, int H, int heads) {
+// NW waves = NW * 16 query rows per workgroup: 4 for short sequences, 8 (128 queries share every K/V tile)
+// from 128 tokens on.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens,
+                                                           bf16_t* __restrict__ ctx, int S, int H, int heads) {
+    constexpr int QB = NW * 16;
     __shared__ __attribute__((aligned(16))) char sKV[2][2 * 64 * ROWB];    // [buffer][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qblocks = (S + 63) / 64;
+    const int qblocks = (S + QB - 1) / QB;
     const int qb = blockIdx.x % qblocks;
     const int head = (blockIdx.x / qblocks) % heads;
     const int seq = blockIdx.x / (qblocks * heads);
     const int len = min(lens[seq], S);
-    if (qb * 64 >= len) return;                      // only padded query rows here
+    if (qb * QB >= len) return;                      // only padded query rows here
     const int g = lane >> 4, c = lane & 15;
     const size_t ld = (size_t)3 * H * 2;             // bytes per token row of qkv
     const char* base = reinterpret_cast<const char*>(qkv) + (size_t)seq * S * ld + (size_t)head * 64 * 2;
 
     // Q^T fragments of this wave's 16 query rows (B operand: lane (g,c) holds Q[q = c][d = kk*32 + g*8 ..+8))
-    const int q_row = qb * 64 + wave * 16 + c;
+    const int q_row = qb * QB + wave * 16 + c;
     bf16x8 qf[2];
     {
         const int qr = q_row < S ? q_row : S - 1;
@@ -686,8 +690,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
     // K/V tiles are double buffered: tile t + 1 is fetched while tile t is used (one barrier per tile)
     auto issue_kv = [&](int kv0, int buf) {
-        stage_rows_asm<64, 4>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sKV[buf], wave, lane);                   // K part
-        stage_rows_asm<64, 4>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sKV[buf] + 64 * ROWB, wave, lane);   // V part
+        stage_rows_asm<64, NW>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sKV[buf], wave, lane);                   // K part
+        stage_rows_asm<64, NW>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sKV[buf] + 64 * ROWB, wave, lane);   // V part
     };
     issue_kv(0, 0);
     int buf = 0;
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float l_q = __shfl(l, g * 4 + r, 64);
-        const int q = qb * 64 + wave * 16 + g * 4 + r;
+        const int q = qb * QB + wave * 16 + g * 4 + r;
         if (q < len) {
             bf16_t* dst = ctx + ((size_t)seq * S + q) * H + head * 64;
 #pragma unroll
@@ -1064,7 +1068,8 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
                        enc->type.as<bf16_t>(), enc->emb_g.as<float>(), enc->emb_b.as<float>(), enc->pre.as<float>(),
                        enc->x.as<bf16_t>(), T, S, H, c.vocab_size, c.ln_eps);
     SQE_HIP(hipGetLastError());
-    const int qblocks = (S + 63) / 64;
+    const int att_nw = S >= 128 ? 8 : 4;
+    const int qblocks = (S + att_nw * 16 - 1) / (att_nw * 16);
     for (int l = 0; l < c.layers; ++l) {
         sqe_layer& L = *enc->layers[l];
         GemmArgs a;
@@ -1073,8 +1078,12 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
         a.W = L.w_qkv.as<bf16_t>(); a.X = enc->x.as<bf16_t>(); a.bias = L.b_qkv.as<float>(); a.out = enc->qkv.p; a.N = 3 * H; a.K = H;
         SQE_TRY(launch_gemm<EPI_BIAS>(a, t_pad, cus, st));
         // E3: attention
-        hipLaunchKernelGGL(attention_kernel, dim3(B * c.heads * qblocks), dim3(256), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
-                           enc->att.as<bf16_t>(), S, H, c.heads);
+        if (att_nw == 8)
+            hipLaunchKernelGGL(attention_kernel<8>, dim3(B * c.heads * qblocks), dim3(512), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
+                               enc->att.as<bf16_t>(), S, H, c.heads);
+        else
+            hipLaunchKernelGGL(attention_kernel<4>, dim3(B * c.heads * qblocks), dim3(256), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
+                               enc->att.as<bf16_t>(), S, H, c.heads);
         SQE_HIP(hipGetLastError());
         // E4: output projection + residual, LayerNorm
         a.W = L.w_o.as<bf16_t>(); a.X = enc->att.as<bf16_t>(); a.bias = L.b_o.as<float>(); a.resid = enc->x.as<bf16_t>();
