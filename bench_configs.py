@@ -29,6 +29,32 @@ D = 1024
 BLOCK = 1 << 20
 
 
+BERT_LARGE = dict(vocab_size=30522, hidden=1024, layers=24, heads=16, inter=4096, max_pos=512, type_vocab=2)
+
+
+def random_bert_weights(cfg=BERT_LARGE, seed: int = 0):
+    """Seeded N(0, 0.02) BERT parameters by BertModel state-dict name (LayerNorm weights around 1): the model
+    geometry the reference's embedding model has, with random values -- no checkpoint exists offline."""
+    h, i = cfg["hidden"], cfg["inter"]
+    shapes = {"embeddings.word_embeddings.weight": (cfg["vocab_size"], h), "embeddings.position_embeddings.weight": (cfg["max_pos"], h),
+              "embeddings.token_type_embeddings.weight": (cfg["type_vocab"], h), "embeddings.LayerNorm.weight": (h,),
+              "embeddings.LayerNorm.bias": (h,)}
+    for l in range(cfg["layers"]):
+        p = f"encoder.layer.{l}."
+        for nm in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            shapes[p + nm + ".weight"], shapes[p + nm + ".bias"] = (h, h), (h,)
+        shapes[p + "intermediate.dense.weight"], shapes[p + "intermediate.dense.bias"] = (i, h), (i,)
+        shapes[p + "output.dense.weight"], shapes[p + "output.dense.bias"] = (h, i), (h,)
+        for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
+            shapes[p + nm + ".weight"], shapes[p + nm + ".bias"] = (h,), (h,)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in shapes.items():
+        w = (0.02 * rng.standard_normal(shape)).astype(np.float32)
+        out[name] = w + 1.0 if name.endswith("LayerNorm.weight") else w
+    return out
+
+
 def timed(fn, sync, iters, warmup=2):
     for _ in range(warmup):
         fn()
@@ -59,16 +85,14 @@ def build_random_index(ctx, rows, dev, kind=0, nlist=0, clustered=None):
 
 
 def mode_e2e(args, ctx, dev):
-    from oracle import bert as OB          # seeded weight recipe only (test infrastructure used as data generator)
     from semantic_query_engine_amd.encoder import BertEncoder
-    cfg = OB.BertCfg()
     enc = BertEncoder(ctx)
-    enc.load_weights({k: v.numpy() for k, v in OB.random_weights(cfg, seed=0).items()})
+    enc.load_weights(random_bert_weights())
     idx = build_random_index(ctx, args.rows, dev)
     out = {"mode": "e2e", "rows": args.rows, "batch": 64, "k": 10, "cases": []}
     for s in (16, 32, 128):
         g = torch.Generator(device=dev).manual_seed(s)
-        ids = torch.randint(1000, cfg.vocab_size, (64, s), generator=g, device=dev, dtype=torch.int32)
+        ids = torch.randint(1000, BERT_LARGE["vocab_size"], (64, s), generator=g, device=dev, dtype=torch.int32)
         lens = torch.full((64,), s, device=dev, dtype=torch.int32)
         emb = torch.empty((64, D), device=dev)
         cos = torch.empty((64, 10), device=dev)
@@ -83,14 +107,12 @@ def mode_e2e(args, ctx, dev):
 
 
 def mode_encode(args, ctx, dev):
-    from oracle import bert as OB
     from semantic_query_engine_amd.encoder import BertEncoder
-    cfg = OB.BertCfg()
     enc = BertEncoder(ctx)
-    enc.load_weights({k: v.numpy() for k, v in OB.random_weights(cfg, seed=0).items()})
+    enc.load_weights(random_bert_weights())
     b, s = args.batch, 512
     g = torch.Generator(device=dev).manual_seed(1)
-    ids = torch.randint(1000, cfg.vocab_size, (b, s), generator=g, device=dev, dtype=torch.int32)
+    ids = torch.randint(1000, BERT_LARGE["vocab_size"], (b, s), generator=g, device=dev, dtype=torch.int32)
     lens = torch.full((b,), s, device=dev, dtype=torch.int32)
     emb = torch.empty((b, D), device=dev)
     torch.cuda.synchronize()
@@ -163,18 +185,16 @@ def mode_ingest(args, ctx, dev):
     normalise + index, through the reference-named bulk call (`embed_texts_in_batches`, main.py:148-169) and
     `OpenSearchIndexer.add_embeddings` (main.py:309-338).  Synthetic text over a synthetic 8k-word vocabulary."""
     import asyncio
-    from oracle import bert as OB
     from semantic_query_engine_amd import retrieval as RT
     from semantic_query_engine_amd.encoder import BertEncoder
     from semantic_query_engine_amd.tokenizer import WordPieceTokenizer
-    cfg = OB.BertCfg()
     enc = BertEncoder(ctx)
-    enc.load_weights({k: v.numpy() for k, v in OB.random_weights(cfg, seed=0).items()})
+    enc.load_weights(random_bert_weights())
     rng = np.random.default_rng(0)
     letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
     words = sorted({"".join(rng.choice(letters, rng.integers(3, 10))) for _ in range(9000)})[:8000]
     vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + ["##" + w[:3] for w in words[:2000]]
-    vocab += [f"[unused{i}]" for i in range(cfg.vocab_size - len(vocab))]
+    vocab += [f"[unused{i}]" for i in range(BERT_LARGE["vocab_size"] - len(vocab))]
     tok = WordPieceTokenizer(vocab_text="\n".join(vocab) + "\n")
     RT.configure_embedder(RT.Embedder(enc, tok))
     n = args.batch if args.batch != 1024 else 2048
@@ -199,7 +219,7 @@ def mode_ingest(args, ctx, dev):
 
 
 def mode_cache(args, ctx, dev):
-    from oracle import retrieval as R
+    from oracle import retrieval as R      # CPU baseline leg only: the reference's Python loop, restated (main.py:73-87)
     from semantic_query_engine_amd.retrieval import SemanticLfuCache
     rng = np.random.default_rng(0)
     m = rng.standard_normal((1000, D)).astype(np.float32)
