@@ -36,7 +36,7 @@ struct ScanPlan {
     int b_pad;            // qblocks * bn
     int n_tiles;          // ceil(n_rows / SCAN_BM)
     int n_chunks;         // DB chunks (persistent workgroups per query block)
-    int tiles_per_chunk;  // ceil(n_tiles / n_chunks)
+    int tiles_per_chunk;  // ceil(n_tiles / n_chunks): the longest chunk (tiles are dealt out evenly)
     int kp;               // candidates kept per (chunk, query)
     int ngroups;          // chunk c publishes its maxima to gmax[q][c % ngroups][c / ngroups]
     int gshift;           // log2 group size of the global bound (64 >> gshift >= kp); -1 = off

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         if (batch < p.collect_lo || batch > p.collect_hi) return;
     }
 
-    const int tile_begin = chunk * p.tiles_per_chunk;
-    const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
+    int tile_begin, tile_end;
+    chunk_tile_range(p.n_tiles, p.n_chunks, chunk, tile_begin, tile_end);
     const int nt = tile_end - tile_begin;
     const int KS = p.K / SCAN_BK;
     const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
@@ -183,12 +183,15 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 
     int entry = 0;
     int ks = 0;
-    int refresh_pending = -1;      // slice fetched during the previous K step
+    int refresh_pending = -1;      // slice whose fetch is in flight
+    int refresh_age = 0;           // K steps since it was issued
     int refresh_ctr = 0;
     for (int s = 0; s < total_stages; ++s) {
         char* cur = smem + (s % NST) * STAGE_BYTES;
         // the bound rows fetched during the previous K step have landed (barrier below)
-        if (refresh_pending >= 0) {
+        // The fetch is younger than the DMA pieces of its own K step, so the counted wait that ends that
+        // step leaves it in flight; the wait of the NEXT step retires it (NST = 2 drains everything every step).
+        if (refresh_pending >= 0 && ++refresh_age >= (NST == 2 ? 1 : 2)) {
             if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, lane);
             refresh_pending = -1;
         }
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             // Bound refresh schedule: entry 1 fetches every slice back to back from K step KS/4 on
             // (after every chunk has published its boot maxima); later one slice per tile.
             const bool want = entry == 1 ? (ks >= KS / 4 && refresh_ctr < NSLICE) : (entry > 1 && ks == 0);
-            if (want && p.gshift >= 0 && !collect) {
+            if (want && p.gshift >= 0 && !collect && refresh_pending < 0) {
+                refresh_age = 0;
                 refresh_pending = refresh_ctr % NSLICE;
                 ++refresh_ctr;
                 refresh_issue<true>(gmax_group, f.gstride, refresh_pending, gstage, wave, lane);
@@ -332,9 +336,10 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     if (chunks < 1) chunks = 1;
     // a multiple of 64 chunks fills the 64 columns of the global-bound table
     if (chunks >= GMAX_COLS) chunks = chunks / GMAX_COLS * GMAX_COLS;
-    if (chunks > p.n_tiles) chunks = p.n_tiles > 0 ? p.n_tiles : 1;
+    if (chunks > p.n_tiles) chunks = p.n_tiles >= GMAX_COLS ? p.n_tiles / GMAX_COLS * GMAX_COLS : (p.n_tiles > 0 ? p.n_tiles : 1);
+    // tiles are dealt out evenly (chunk_tile_range): exactly `chunks` chunks, none empty
+    p.n_chunks = chunks;
     p.tiles_per_chunk = p.n_tiles > 0 ? (p.n_tiles + chunks - 1) / chunks : 0;
-    p.n_chunks = p.tiles_per_chunk > 0 ? (p.n_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk : 1;
     p.kp = kp;
     p.ngroups = (p.n_chunks + GMAX_COLS - 1) / GMAX_COLS;
     // global bound: 64 >> gshift groups, each contributing one distinct row, must be >= kp

@@ -409,8 +409,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
     const int q0 = qb * BN8;
 
-    P.tile_begin = chunk * p.tiles_per_chunk;
-    const int tile_end = min(p.n_tiles, P.tile_begin + p.tiles_per_chunk);
+    int tile_end;
+    chunk_tile_range(p.n_tiles, p.n_chunks, chunk, P.tile_begin, tile_end);
     P.nt = tile_end - P.tile_begin;
     P.KS = p.K / SCAN_BK;
     // entries: 0 = first tile (BOOT), 1..nt-1 = the other tiles, nt = the first tile again

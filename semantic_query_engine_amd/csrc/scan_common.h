@@ -112,6 +112,15 @@ struct Filter {
     int* collect_cnt;
 };
 
+// Tiles [begin, end) of a chunk: the n_tiles are dealt out as evenly as possible, so EVERY one of the
+// n_chunks chunks exists (the global bound needs all 64 columns of a table row published: a plan that
+// rounded the chunk length up could end with fewer chunks than columns and silently lose the bound).
+__device__ __forceinline__ void chunk_tile_range(int n_tiles, int n_chunks, int chunk, int& begin, int& end) {
+    const int base = n_tiles / n_chunks, rem = n_tiles - base * n_chunks;
+    begin = chunk * base + min(chunk, rem);
+    end = begin + base + (chunk < rem ? 1 : 0);
+}
+
 // host: kernel argument block from a plan (scan.hip)
 ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a);
 
