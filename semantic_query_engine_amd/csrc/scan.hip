@@ -328,7 +328,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
 
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     ScanPlan p;
-    p.bn = B > 64 ? 256 : 64;
+    p.bn = B > 128 ? 256 : B > 64 ? 128 : 64;          // 128: HBM-bound like 64, half the padding of a 256 block
     p.qblocks = (B + p.bn - 1) / p.bn;
     p.b_pad = p.qblocks * p.bn;
     p.n_tiles = (int)((n_rows + SCAN_BM - 1) / SCAN_BM);
@@ -351,6 +351,7 @@ int launch_scan_collect(const ScanPlan& plan, const ScanArgs& a, hipStream_t str
     if (!a.collect_thr || !a.collect_keys || !a.collect_cnt || !a.unc_count)
         return fail(SQE_ERR_INVALID, "scan collect: missing buffers");
     if (plan.bn == 256) return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream, true);
+    if (plan.bn == 128) return launch_cfg<4, 2, 4, 4, 2>(plan, a, stream, true);
     return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream, true);
 }
 
@@ -372,6 +373,7 @@ int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream
         if (which == 2) return launch_scan_bf16_pp(plan, a, stream);
         return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream);
     }
+    if (plan.bn == 128) return launch_cfg<4, 2, 4, 4, 2>(plan, a, stream);
     return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream);
 }
 
