@@ -13,9 +13,10 @@
 //     (blocks b and b+8 share an XCD): a DB tile fetched by one of them is an L2 hit for
 //     the others while they run in step.
 //
-// This file holds the generic two-stage form (one barrier per 64-wide K step, double
-// buffered global_load_lds staging) used for small query blocks; scan8.hip holds the deeper
-// pipeline used for 256-query blocks.  Both operand tiles go global -> LDS in full 128-B
+// This file holds the generic staged form (one barrier per 64-wide K step; LDS ring of 2 stages for the
+// 256- and 128-query tiles, 3 for the HBM-bound 64-query tile): the kernel of batches <= 128 and of the
+// collect pass, and the A/B baseline for 256-query blocks, whose default is the ping-pong schedule of
+// scan_pp.hip (scan8.hip holds a third schedule).  Both operand tiles go global -> LDS in full 128-B
 // lines; the XOR chunk swizzle c' = c ^ ((row >> 1) & 7) is applied on the per-lane SOURCE
 // address and on the ds_read_b128 address (the LDS image itself stays lane-linear), which
 // makes every fragment read bank-conflict free.
