@@ -497,6 +497,18 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
     }
     sqe_ctx* c = idx->ctx;
     const int K = idx->dim;
+    // More than four 256-query blocks would leave fewer than 64 DB chunks (one workgroup per CU), too few to
+    // fill a row of the global-bound table: the filter would lose its cross-chunk threshold.  Larger batches
+    // run as passes of 1024 queries, each at the full-batch rate.
+    constexpr int MAX_PASS = 1024;
+    if (B > MAX_PASS) {
+        for (int off = 0; off < B; off += MAX_PASS) {
+            const int m = std::min(MAX_PASS, B - off);
+            SQE_TRY(sqe_index_search_device(idx, q_dev + (size_t)off * K, m, k, nprobe, cos_out_dev + (size_t)off * k,
+                                            id_out_dev + (size_t)off * k));
+        }
+        return SQE_OK;
+    }
     const int kp = auto_kp(idx, k);
     const ScanPlan plan = make_scan_plan(idx->n, B, kp, c->cu_count);
 

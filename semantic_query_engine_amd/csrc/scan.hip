@@ -124,8 +124,8 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
     f.gstride = p.ngroups * GMAX_COLS * 64;
-    const uint32_t* gmax_group = p.gmax + ((size_t)(q0 / 64) * p.ngroups + (chunk % p.ngroups)) * (GMAX_COLS * 64);
-    f.gmax_mine = const_cast<uint32_t*>(gmax_group) + (chunk / p.ngroups) * 64;
+    const uint32_t* gmax_group;
+    bound_rows(p, chunk, q0, gmax_group, f.gmax_mine);
     f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL::OFF_THR_KEY);
     f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL::OFF_THR_S);
     f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL::OFF_CNT);
@@ -314,7 +314,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     k.n_tiles = plan.n_tiles; k.tiles_per_chunk = plan.tiles_per_chunk; k.n_chunks = plan.n_chunks;
     k.qblocks = plan.qblocks; k.kp = plan.kp;
     k.trig = plan.kp > 128 ? plan.kp : 128;
-    k.ngroups = plan.ngroups; k.gshift = plan.gshift;
+    k.ngroups = plan.ngroups; k.gshift = plan.gshift; k.gcomplete = plan.n_chunks / GMAX_COLS;
     {
         static const int krot = [] { const char* e = getenv("SQE_KROT"); return e ? atoi(e) : 0; }();
         static const int dbg = [] { const char* e = getenv("SQE_DBG"); return e ? atoi(e) : 0; }();
@@ -335,9 +335,9 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     p.n_tiles = (int)((n_rows + SCAN_BM - 1) / SCAN_BM);
     int chunks = cu_count / p.qblocks;                 // one persistent workgroup per CU
     if (chunks < 1) chunks = 1;
-    // a multiple of 64 chunks fills the 64 columns of the global-bound table
-    if (chunks >= GMAX_COLS) chunks = chunks / GMAX_COLS * GMAX_COLS;
-    if (chunks > p.n_tiles) chunks = p.n_tiles >= GMAX_COLS ? p.n_tiles / GMAX_COLS * GMAX_COLS : (p.n_tiles > 0 ? p.n_tiles : 1);
+    // chunk c publishes to row c / 64, column c % 64 of the global-bound table; the rows that are complete
+    // (64 chunks) serve as bound for everybody, so the chunk count need not be a multiple of 64
+    if (chunks > p.n_tiles) chunks = p.n_tiles > 0 ? p.n_tiles : 1;
     // tiles are dealt out evenly (chunk_tile_range): exactly `chunks` chunks, none empty
     p.n_chunks = chunks;
     p.tiles_per_chunk = p.n_tiles > 0 ? (p.n_tiles + chunks - 1) / chunks : 0;
@@ -345,6 +345,7 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     p.ngroups = (p.n_chunks + GMAX_COLS - 1) / GMAX_COLS;
     // global bound: 64 >> gshift groups, each contributing one distinct row, must be >= kp
     p.gshift = kp <= 16 ? 2 : kp <= 32 ? 1 : kp <= 64 ? 0 : -1;
+    if (p.n_chunks < GMAX_COLS) p.gshift = -1;          // no complete row: no cross-chunk bound
     return p;
 }
 

@@ -427,8 +427,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_p8_kernel(ScanKernelAr
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
     f.gstride = p.ngroups * GMAX_COLS * 64;
-    P.gmax_group = p.gmax + ((size_t)(q0 / 64) * p.ngroups + (chunk % p.ngroups)) * (GMAX_COLS * 64);
-    f.gmax_mine = const_cast<uint32_t*>(P.gmax_group) + (chunk / p.ngroups) * 64;
+    bound_rows(p, chunk, q0, P.gmax_group, f.gmax_mine);
     f.thr_key = reinterpret_cast<uint64_t*>(smem + OFF_F + FL8::OFF_THR_KEY);
     f.thr_s = reinterpret_cast<float*>(smem + OFF_F + FL8::OFF_THR_S);
     f.cnt = reinterpret_cast<int*>(smem + OFF_F + FL8::OFF_CNT);

@@ -46,7 +46,9 @@ struct ScanKernelArgs {
     int qblocks;
     int kp;
     int trig;            // compaction trigger (kp <= trig <= CAND_CAP - SCAN_BM)
-    int ngroups;         // chunk c publishes to gmax[q][c % ngroups][c / ngroups]
+    int ngroups;         // chunk c publishes to gmax[q][c / 64][c % 64]
+    int gcomplete;       // groups whose 64 columns all exist (n_chunks / 64); chunks of a partial last group read
+                         //   their bound from a complete one (any complete row = 64 distinct rows of the index)
     int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
     int krot;            // workgroup w walks K rotated by w * krot steps
     int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter,
@@ -119,6 +121,15 @@ __device__ __forceinline__ void chunk_tile_range(int n_tiles, int n_chunks, int 
     const int base = n_tiles / n_chunks, rem = n_tiles - base * n_chunks;
     begin = chunk * base + min(chunk, rem);
     end = begin + base + (chunk < rem ? 1 : 0);
+}
+
+// Table rows of chunk `chunk`: the one it publishes to (+ its column) and the one it reads its bound from.
+__device__ __forceinline__ void bound_rows(const ScanKernelArgs& p, int chunk, int q0, const uint32_t*& read_row, uint32_t*& mine) {
+    const int grp = chunk / GMAX_COLS, col = chunk % GMAX_COLS;
+    const int rgrp = (p.gcomplete <= 0 || grp < p.gcomplete) ? grp : grp % p.gcomplete;
+    uint32_t* slice0 = p.gmax + (size_t)(q0 / 64) * p.ngroups * (GMAX_COLS * 64);
+    read_row = slice0 + (size_t)rgrp * (GMAX_COLS * 64);
+    mine = slice0 + (size_t)grp * (GMAX_COLS * 64) + col * 64;
 }
 
 // host: kernel argument block from a plan (scan.hip)

@@ -155,14 +155,14 @@ def test_profiling_stats(ctx):
     assert st["scan_flops"] == 2 * 4096 * 1024 * 8 and st["scan_rows"] == 4096
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_shape_sweep(ctx, seed):
     """Seeded sweep over dimension, row count (tile edges, several chunks), batch (both scan kernels, padded
     query blocks) and k (up to the 256 limit), with planted exact matches and duplicated rows."""
     rng = np.random.default_rng(1000 + seed)
     d = int(rng.choice([64, 128, 192, 512, 1024, 2048]))
     n = int(rng.choice([255, 256, 257, 511, 513, 4097, 16384, 70001, 131072 + 255]))
-    b = int(rng.choice([1, 2, 63, 64, 65, 100, 128, 129, 255, 256, 257, 300]))
+    b = int(rng.choice([1, 2, 63, 64, 65, 100, 128, 129, 255, 256, 257, 300, 700, 1100]))
     k = int(rng.choice([1, 3, 10, 64, 100, 256]))
     x = rng.standard_normal((n, d)).astype(np.float32)
     if n > 600:
