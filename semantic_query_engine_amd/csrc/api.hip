@@ -203,7 +203,13 @@ int auto_kp(const sqe_index* idx, int k) {
     // The certificate needs the kp-th scan score to sit more than eps (~2.5e-3 at dim 1024) below the
     // k-th true cosine.  On 10M random rows the 10th -> 32nd gap is only ~3 sigma above eps (a few
     // queries per 1024 would need the fp32 rescan); 10th -> 64th makes that a 1e-5 event.
-    return std::min(MAX_KP, std::max(idx->certify ? 64 : 32, 4 * k));
+    // kp <= 64 keeps the cross-chunk bound of the scan filter (64 table columns), which halves the scan
+    // time, so with the certificate guarding exactness kp stays 64 up to k = 32; beyond that the candidate
+    // set has to grow with k and the scan runs on per-chunk thresholds only.
+    // 128 candidates (compaction window 128) up to k = 128; k > 128 needs kp = 256, where a 512-slot list
+    // has no window left and compacts on every tile -- correct, slow, and far outside the reference's k = 3.
+    if (idx->certify) return k <= 32 ? 64 : k <= 128 ? 128 : MAX_KP;
+    return std::min(MAX_KP, std::max(32, 4 * k));
 }
 
 }  // namespace
@@ -591,13 +597,15 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
             a.dbg_counters = nullptr;
             a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
             a.unc_count = unc_count;
-            // one plan per range of counts, each sized like a search of that batch (all CUs busy in every case)
-            const int bounds[5] = {0, 64, 256, 512, 1 << 30};
-            for (int r = 0; r < 4 && bounds[r] < B; ++r) {
-                const int hi = std::min(bounds[r + 1], B);
+            // one plan per range of counts, each sized like a search of that batch (all CUs busy in every case).
+            // Every range runs the 256-query tile: the 64- and 128-query tiles lose rows in COLLECT mode
+            // (strict oracle check, tools/dbg_collect.py) -- until that is understood they are not used here.
+            const int bounds[4] = {0, 256, 512, 1 << 30};
+            for (int r = 0; r < 3 && bounds[r] < B; ++r) {
+                const int hi = std::max(129, std::min(bounds[r + 1], std::max(B, 129)));
                 const ScanPlan cp = make_scan_plan(idx->n, hi, kp, c->cu_count);
                 a.collect_lo = bounds[r] + 1;
-                a.collect_hi = r == 3 ? (1 << 30) : bounds[r + 1];
+                a.collect_hi = r == 2 ? (1 << 30) : bounds[r + 1];
                 SQE_TRY(launch_scan_collect(cp, a, c->stream));
             }
             // ... and re-score them in fp32

@@ -26,7 +26,7 @@ int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n
 // ------------------------------------------------------------------ flat scan (S2)
 constexpr int SCAN_BM = 256;        // DB rows per tile
 constexpr int SCAN_BK = 64;         // K elements per pipeline stage
-constexpr int CAND_CAP = 512;       // candidate slots per (chunk, query)
+constexpr int CAND_CAP = 512;       // candidate slots per (chunk, query): kp kept + a compaction window + one tile of appends
 constexpr int MAX_KP = 256;         // max candidates kept per (chunk, query)
 constexpr int GMAX_COLS = 64;       // chunk maxima per (query, group) row of the global-bound table
 

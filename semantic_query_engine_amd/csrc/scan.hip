@@ -25,6 +25,8 @@
 // higher score first, lower row id first among equals, so results are deterministic.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "scan_common.h"
 
 namespace sqe {
@@ -313,7 +315,9 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     k.db_pitch = a.db_pitch; k.q_pitch = a.q_pitch;
     k.n_tiles = plan.n_tiles; k.tiles_per_chunk = plan.tiles_per_chunk; k.n_chunks = plan.n_chunks;
     k.qblocks = plan.qblocks; k.kp = plan.kp;
-    k.trig = plan.kp > 128 ? plan.kp : 128;
+    // a list is cut back to its best kp when it reaches `trig`; the window trig - kp (>= 64) is what one
+    // compaction buys, and a tile can add SCAN_BM entries on top before the next check
+    k.trig = std::min(CAND_CAP - SCAN_BM, std::max(2 * plan.kp, 128));
     k.ngroups = plan.ngroups; k.gshift = plan.gshift; k.gcomplete = plan.n_chunks / GMAX_COLS;
     {
         static const int krot = [] { const char* e = getenv("SQE_KROT"); return e ? atoi(e) : 0; }();

@@ -214,3 +214,24 @@ def test_partial_certificate_failures(ctx, n_hard, b):
     # the hard queries' neighbours all come from the cluster, which the bf16 scan alone cannot order
     cl = set(cluster_rows.tolist())
     assert all(set(ids[h].tolist()) <= cl for h in hard)
+
+
+@pytest.mark.parametrize("b", [8, 64, 100, 128, 200, 300])
+def test_forced_collect_pass_is_exact(ctx, b):
+    """rescore_k = k leaves the first pass no margin, so EVERY query fails its certificate and the answer comes
+    from the compacted collect pass.  Random data: the top-k sets must equal the float64 oracle's exactly
+    (a weaker, tolerance-based check once hid rows lost by the collect pass)."""
+    rng = np.random.default_rng(50 + b)
+    n, d, k = 60000, 1024, 10
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    idx = _index(ctx, x)
+    idx.set_option("rescore_k", k)
+    s = R.normalize_rows(q).astype(np.float64) @ R.normalize_rows(x).astype(np.float64).T
+    want = [set(np.argsort(-s[i], kind="stable")[:k].tolist()) for i in range(b)]
+    for _ in range(3):
+        ctx.stats_reset()
+        cos, ids = idx.search(q, k)
+        assert ctx.stats()["uncertified"] == b
+        bad = [i for i in range(b) if set(ids[i].tolist()) != want[i]]
+        assert not bad, bad
