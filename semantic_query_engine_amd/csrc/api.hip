@@ -597,15 +597,13 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
             a.dbg_counters = nullptr;
             a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
             a.unc_count = unc_count;
-            // one plan per range of counts, each sized like a search of that batch (all CUs busy in every case).
-            // Every range runs the 256-query tile: the 64- and 128-query tiles lose rows in COLLECT mode
-            // (strict oracle check, tools/dbg_collect.py) -- until that is understood they are not used here.
-            const int bounds[4] = {0, 256, 512, 1 << 30};
-            for (int r = 0; r < 3 && bounds[r] < B; ++r) {
-                const int hi = std::max(129, std::min(bounds[r + 1], std::max(B, 129)));
+            // one plan per range of counts, each sized like a search of that batch (all CUs busy in every case)
+            const int bounds[5] = {0, 64, 256, 512, 1 << 30};
+            for (int r = 0; r < 4 && bounds[r] < B; ++r) {
+                const int hi = std::min(bounds[r + 1], B);
                 const ScanPlan cp = make_scan_plan(idx->n, hi, kp, c->cu_count);
                 a.collect_lo = bounds[r] + 1;
-                a.collect_hi = r == 2 ? (1 << 30) : bounds[r + 1];
+                a.collect_hi = r == 3 ? (1 << 30) : bounds[r + 1];
                 SQE_TRY(launch_scan_collect(cp, a, c->stream));
             }
             // ... and re-score them in fp32

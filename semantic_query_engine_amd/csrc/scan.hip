@@ -182,7 +182,11 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         if (++d_ks == KS) { d_ks = 0; ++d_entry; }
     };
     for (int s = 0; s < NST - 1 && s < total_stages; ++s) issue_stage(s);
-    __syncthreads();   // vmcnt(0) + barrier: prologue stages landed, state initialised
+    // The DMA pieces are inline asm, invisible to hipcc: __syncthreads() alone would NOT wait for them (the
+    // first K step would read LDS before its tile landed -- harmless-looking in the normal pass, whose first
+    // tile only feeds the boot maxima, but rows of the first tile were lost in COLLECT mode).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // prologue stages landed, filter state initialised
 
     int entry = 0;
     int ks = 0;
