@@ -206,9 +206,10 @@ int auto_kp(const sqe_index* idx, int k) {
     // kp <= 64 keeps the cross-chunk bound of the scan filter (64 table columns), which halves the scan
     // time, so with the certificate guarding exactness kp stays 64 up to k = 32; beyond that the candidate
     // set has to grow with k and the scan runs on per-chunk thresholds only.
-    // 128 candidates (compaction window 128) up to k = 128; k > 128 needs kp = 256, where a 512-slot list
-    // has no window left and compacts on every tile -- correct, slow, and far outside the reference's k = 3.
-    if (idx->certify) return k <= 32 ? 64 : k <= 128 ? 128 : MAX_KP;
+    // 128 candidates (compaction window 128) up to k = 128.  Above that the 512-slot lists leave a window of
+    // only 256 - kp entries, so kp = k exactly (largest window; the certificate then fails and the collect
+    // pass supplies the answer) -- far outside the reference's k = 3.
+    if (idx->certify) return k <= 32 ? 64 : k <= 128 ? 128 : k;
     return std::min(MAX_KP, std::max(32, 4 * k));
 }
 
