@@ -133,7 +133,11 @@ __global__ void ivf_scatter_kernel(const int* __restrict__ assign, int64_t n, co
 
 // top-nprobe lists of a query from its dense coarse scores [nlist] (score desc, list id asc); one workgroup
 // per query, scores staged in LDS, byte-wise radix select on (orderable score, ~id) keys
+// The GEMM scores come from bf16 operands: the best nprobe + 8 by those scores are re-scored in fp32 (raw query
+// row against the normalised fp32 centroid; dividing by the query norm does not change the order) and the
+// best nprobe of them returned, so the list order is the exact fp32 one.
 __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __restrict__ scores, int nlist, int nprobe,
+                                                               const float* __restrict__ rows, const float* __restrict__ cent, int dim,
                                                                int64_t* __restrict__ probes, float* __restrict__ probes_cos) {
     extern __shared__ __attribute__((aligned(16))) float ssc[];      // [nlist]
     __shared__ int hist[256];
@@ -143,9 +147,10 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
     for (int i = tid; i < nlist; i += 256) ssc[i] = scores[(size_t)q * nlist + i];
     __syncthreads();
     auto key_of = [&](int i) { return make_key(ssc[i] + 0.0f, (uint32_t)i); };
+    const int nsel = min(min(nprobe + 8, MAX_KP), nlist);      // candidates kept for the fp32 re-score
     uint64_t prefix = 0;
-    int remaining = nprobe;
-    const bool all = nlist <= nprobe;
+    int remaining = nsel;
+    const bool all = nlist <= nsel;
     for (int byte = 7; byte >= 0 && !all; --byte) {
         hist[tid] = 0;
         __syncthreads();
@@ -180,15 +185,41 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
         }
     }
     __syncthreads();
-    const int m = min(scratch[2], nprobe);
+    const int m = min(scratch[2], nsel);
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const float4* qv = reinterpret_cast<const float4*>(rows + (size_t)q * dim);
+        const int nvec = dim >> 2;
+        float qq = 0.f;
+        for (int v4 = lane; v4 < nvec; v4 += 64) {
+            const float4 b = qv[v4];
+            qq = fmaf(b.x, b.x, qq); qq = fmaf(b.y, b.y, qq); qq = fmaf(b.z, b.z, qq); qq = fmaf(b.w, b.w, qq);
+        }
+        const float inv = 1.0f / (sqrtf(wave_sum(qq)) + 1e-9f);
+        for (int e = wave; e < m; e += 4) {
+            const uint32_t id = key_row(top[e]);
+            const float4* cv = reinterpret_cast<const float4*>(cent + (size_t)id * dim);
+            float s = 0.f;
+            for (int v4 = lane; v4 < nvec; v4 += 64) {
+                const float4 a = cv[v4], b = qv[v4];
+                s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+            }
+            s = wave_sum(s) * inv + 0.0f;
+            if (lane == 0) top[e] = make_key(s, id);
+        }
+    }
+    __syncthreads();
+    const int mk = min(m, nprobe);
     for (int i = tid; i < m; i += 256) {
         const uint64_t ki = top[i];
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += top[j] > ki ? 1 : 0;
-        probes[(size_t)q * nprobe + rank] = (int64_t)key_row(ki);
-        probes_cos[(size_t)q * nprobe + rank] = key_score(ki);
+        if (rank < nprobe) {
+            probes[(size_t)q * nprobe + rank] = (int64_t)key_row(ki);
+            probes_cos[(size_t)q * nprobe + rank] = key_score(ki);
+        }
     }
-    for (int i = m + tid; i < nprobe; i += 256) {
+    for (int i = mk + tid; i < nprobe; i += 256) {
         probes[(size_t)q * nprobe + i] = -1;
         probes_cos[(size_t)q * nprobe + i] = -INFINITY;
     }
@@ -658,7 +689,7 @@ static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev,
     sqe_ctx* ctx = index_ctx(base);
     hipStream_t s = ctx_stream(ctx);
     const int nlist = index_nlist(base), dim = index_dim(base);
-    const bool dense = nlist % 128 == 0 && (size_t)nlist * 4 <= 64 * 1024 && kk <= MAX_KP;
+    const bool dense = nlist % 128 == 0 && (size_t)nlist * 4 <= 64 * 1024 && kk + 8 <= MAX_KP;
     if (!dense) return sqe_index_search_device(st->coarse, rows_dev, (int)b, kk, 0, cos_out, ids_out);
     if (st->cent_dirty) {
         SQE_TRY(st->cent_bf16.ensure((size_t)nlist * dim * 2));
@@ -683,7 +714,7 @@ static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev,
         SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, m, t_pad,
                                    ctx_cu_count(ctx), s));
         hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(m), dim3(256), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, kk,
-                           ids_out + off * kk, cos_out + off * kk);
+                           rows_dev + (size_t)off * dim, index_master(st->coarse), dim, ids_out + off * kk, cos_out + off * kk);
         SQE_HIP(hipGetLastError());
     }
     return SQE_OK;

@@ -22,9 +22,10 @@ def ctx():
     return Context(0)
 
 
-def test_ivf_matches_oracle_and_recall(ctx):
+@pytest.mark.parametrize("nlist", [64, 128])     # 64: coarse search through the flat scan; 128: dense coarse GEMM
+def test_ivf_matches_oracle_and_recall(ctx, nlist):
     from semantic_query_engine_amd import INDEX_IVF_FLAT, VectorIndex
-    n, d, nlist, k = 30000, 128, 64, 10
+    n, d, k = 30000, 128, 10
     x, cen = _clustered(n, d, 200, seed=1)
     rng = np.random.default_rng(2)
     q = (x[rng.integers(0, n, 48)] + 0.2 * rng.standard_normal((48, d))).astype(np.float32)
@@ -43,11 +44,11 @@ def test_ivf_matches_oracle_and_recall(ctx):
     best = (xn.astype(np.float64) @ centroids.astype(np.float64).T)
     gap = best.max(1) - best[np.arange(n), assign]
     assert np.all(gap < 2e-6)
-    for nprobe in (1, 8, 64):
+    for nprobe in (1, 8, nlist):
         cos, ids = idx.search(q, k, nprobe=nprobe)
         ref_cos, ref_ids = R.ivf_search(xn, qn, centroids, assign, k, nprobe)
         assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
-    # nprobe = nlist is the exact search; nprobe = 8 of 64 already recalls >= 0.95 on clustered data
+    # nprobe = nlist is the exact search; nprobe = 8 already recalls >= 0.95 on clustered data
     exact_cos, exact_ids = R.exact_topk(xn, qn, k)
     cos, ids = idx.search(q, k, nprobe=nlist)
     assert R.recall_at_k(ids, exact_ids) == 1.0
