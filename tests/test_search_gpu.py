@@ -235,3 +235,33 @@ def test_forced_collect_pass_is_exact(ctx, b):
         assert ctx.stats()["uncertified"] == b
         bad = [i for i in range(b) if set(ids[i].tolist()) != want[i]]
         assert not bad, bad
+
+
+def test_random_session_against_oracle(ctx):
+    """One index through a seeded sequence of adds, in-place updates and searches with changing batch size,
+    k and candidate depth (certified and forced-collect searches interleaved): internal buffers are reused
+    across calls of different shapes, every answer must match the oracle on the rows present at that time."""
+    from semantic_query_engine_amd import VectorIndex
+    rng = np.random.default_rng(2024)
+    d = 192
+    idx = VectorIndex(ctx, d)
+    x = np.zeros((0, d), np.float32)
+    for step in range(14):
+        add = rng.standard_normal((int(rng.choice([1, 300, 5000, 20000])), d)).astype(np.float32)
+        idx.add(add)
+        x = np.concatenate([x, add], 0)
+        if x.shape[0] > 10 and step % 3 == 1:
+            rows = rng.choice(x.shape[0], 5, replace=False)
+            new = rng.standard_normal((5, d)).astype(np.float32)
+            idx.update(rows, new)
+            x[rows] = new
+        b = int(rng.choice([1, 7, 64, 90, 130, 400]))
+        k = int(rng.choice([1, 5, 10, 40]))
+        q = rng.standard_normal((b, d)).astype(np.float32)
+        if x.shape[0] > 3:
+            q[0] = 1.7 * x[rng.integers(0, x.shape[0])]
+        idx.set_option("rescore_k", float(k if step % 4 == 2 else 0))      # every fourth search: all queries collected
+        cos, ids = idx.search(q, k)
+        ref_cos, ref_ids = R.knn_search(x, q, k)
+        assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    assert len(idx) == x.shape[0]
