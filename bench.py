@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--cpu-hnsw-rows", type=int, default=20_000, help="rows of the CPU HNSW baseline (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference timing")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal on a one-GPU box: launched through torch.distributed.run with ONE rank, take the "
+                         "all-gather + merge path of the N > 1 search anyway")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,7 +207,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_collective and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=device)
@@ -249,7 +252,8 @@ def main():
             del x
     torch.cuda.synchronize()
 
-    searcher = ShardedSearcher(ctx, idx, id_base=row_lo, dist=dist, world=world, device=device)
+    searcher = ShardedSearcher(ctx, idx, id_base=row_lo, dist=dist, world=world, device=device,
+                               force_collective=args.force_collective)
 
     def step():
         return searcher.search(q, k)
@@ -335,6 +339,8 @@ def main():
                          "select_rescore": round(st["select_ms"] / args.steps, 4)},
             "roofline": roof,
         }
+        if args.force_collective:
+            out["config"]["rehearsal"] = "one-rank nccl group, all-gather + merge path forced"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, b, n_total, k)
             if args.cpu_hnsw_rows > 0:

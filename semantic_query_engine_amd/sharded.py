@@ -34,8 +34,11 @@ class ShardedSearcher:
     which is how the CPU/gloo protocol tests drive this class without a GPU."""
 
     def __init__(self, ctx, index, id_base: int = 0, dist=None, world: int = 1,
-                 device: Optional[torch.device] = None, group=None):
+                 device: Optional[torch.device] = None, group=None, force_collective: bool = False):
         self.ctx, self.index, self.dist, self.world, self.group = ctx, index, dist, world, group
+        # a one-rank group still takes the all-gather + merge path when asked to: that is how the RCCL
+        # leg is rehearsed on a one-GPU box (tests/test_sharded_gpu.py, bench.py --force-collective)
+        self.collective = dist is not None and (world > 1 or force_collective)
         self.device = device or torch.device("cuda", ctx.device)
         index.set_option("id_base", float(id_base))
         self._bufs = {}
@@ -54,7 +57,7 @@ class ShardedSearcher:
             part = packed_part_bytes(b, k)
             local = torch.empty(part, dtype=torch.uint8, device=self.device)
             gathered = torch.empty(part * self.world, dtype=torch.uint8, device=self.device) \
-                if self.world > 1 else local
+                if self.collective else local
             cos = torch.empty((b, k), dtype=torch.float32, device=self.device)
             ids = torch.empty((b, k), dtype=torch.int64, device=self.device)
             self._bufs[key] = (part, local, gathered, cos, ids)
@@ -68,7 +71,7 @@ class ShardedSearcher:
         id_ptr = local.data_ptr()
         cos_ptr = id_ptr + b * k * 8
         with self._on_stream():
-            if self.world == 1:
+            if not self.collective:
                 self.index.search_device(q.data_ptr(), b, k, cos.data_ptr(), ids.data_ptr())
                 return cos, ids
             self.index.search_device(q.data_ptr(), b, k, cos_ptr, id_ptr)
