@@ -50,3 +50,15 @@ def test_specials_and_truncation(vocab):
     long = "study " * 2000
     ids = WP.encode(long, v, 512)
     assert len(ids) == 512 and ids[0] == 101 and ids[-1] == 102
+
+
+def test_golden_ids_fixture():
+    """the committed id sequences (tests/golden/make_wordpiece_golden.py)."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wordpiece_ids.json"),
+                       encoding="utf-8"))
+    v = {t: i for i, t in enumerate(g["vocab"])}
+    assert len(g["sentences"]) == 20
+    for s, full, trunc in zip(g["sentences"], g["ids_512"], g["ids_16"]):
+        assert WP.encode(s, v, 512) == full, s
+        assert WP.encode(s, v, 16) == trunc, s

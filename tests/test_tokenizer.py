@@ -66,3 +66,17 @@ def test_invalid_utf8_and_errors(tok_and_vocab):
     assert lib.sqe_tokenize(tok.handle, raw, len(raw), 1, ids, C.byref(n)) != 0       # max_len < 2
     h = C.c_void_p()
     assert lib.sqe_tokenizer_create(b"a\nb\n", 4, C.byref(h)) != 0                   # no specials
+
+
+def test_golden_ids_fixture():
+    """The C++ tokenizer against the committed `tokenizers`-library id sequences (SURVEY 8c vii)."""
+    import json
+    from semantic_query_engine_amd.tokenizer import WordPieceTokenizer
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "wordpiece_ids.json"), encoding="utf-8"))
+    tok = WordPieceTokenizer(vocab_text="\n".join(g["vocab"]) + "\n")
+    for s, full, trunc in zip(g["sentences"], g["ids_512"], g["ids_16"]):
+        assert tok.encode(s, 512) == full, s
+        assert tok.encode(s, 16) == trunc, s
+    ids, lens = tok.encode_batch(g["sentences"] * 4, 512)            # 80 texts: the threaded batch path
+    for i, full in enumerate(g["ids_512"] * 4):
+        assert lens[i] == len(full) and ids[i, :lens[i]].tolist() == full
