@@ -316,7 +316,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None}
-        roof.update({"kernel": "scan_bf16_pp_kernel" if os.environ.get("SQE_SCAN", "pp").startswith("pp") and b > 64 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
+        roof.update({"kernel": "scan_bf16_pp_kernel" if os.environ.get("SQE_SCAN", "pp").startswith("pp") and b > 128 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                      "hbm_gbps": round(gbps, 1), "mfma_tflops": round(tflops, 2)})
         if world == 1:

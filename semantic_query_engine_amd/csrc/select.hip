@@ -128,15 +128,33 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
     // fp32 re-score: one wave per candidate, float4 per lane per step
     const float4* qv = reinterpret_cast<const float4*>(p.qn + (size_t)q * p.K);
     const int nvec = p.K >> 2;
-    for (int i = wave; i < m; i += NW) {
-        const float4* rv = reinterpret_cast<const float4*>(p.master + (size_t)sel_row[i] * p.K);
-        float s = 0.f;
-        for (int v = lane; v < nvec; v += 64) {
-            const float4 a = rv[v], b = qv[v];
-            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+    // (four rows per step: their loads are in flight together, each row keeps its own fmaf chain, so the
+    // sums are the ones a row-at-a-time loop produces)
+    constexpr int RU = 4;
+    for (int i0 = wave * RU; i0 < m; i0 += NW * RU) {
+        const float4* rv[RU];
+        float s[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            rv[u] = reinterpret_cast<const float4*>(p.master + (size_t)sel_row[min(i0 + u, m - 1)] * p.K);
+            s[u] = 0.f;
         }
-        s = wave_sum(s);
-        if (lane == 0) sel_score[i] = s + 0.0f;
+        for (int v = lane; v < nvec; v += 64) {
+            const float4 b = qv[v];
+            float4 a[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) a[u] = rv[u][v];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                s[u] = fmaf(a[u].x, b.x, s[u]); s[u] = fmaf(a[u].y, b.y, s[u]);
+                s[u] = fmaf(a[u].z, b.z, s[u]); s[u] = fmaf(a[u].w, b.w, s[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const float t = wave_sum(s[u]);
+            if (lane == 0 && i0 + u < m) sel_score[i0 + u] = t + 0.0f;
+        }
     }
     __syncthreads();
 
