@@ -72,17 +72,25 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int r, int c) {
 
 // NST = LDS ring depth: NST - 1 K steps of DMA are in flight while one is computed.  2 for the
 // 256-query block (MFMA-bound); 3 for the 64-query block, which is HBM-bound and needs the extra
-// 40 KiB per CU in flight to cover the memory latency.
-template <int WM, int WN, int FM, int FN, bool COLLECT, int NST>
+// 40 KiB per CU in flight to cover the memory latency.  NSTB = ring depth of the query operand alone: the
+// 128-query block keeps DB tiles three deep and query tiles (L2-resident, short latency) two deep, which is
+// what fits in 160 KiB next to the filter state; a shallower query ring is issued first in every step so that
+// the counted wait retires it together with the older DB stage.
+template <int WM, int WN, int FM, int FN, bool COLLECT, int NST, int NSTB = NST>
 __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     constexpr int BM = WM * FM * 16;
     constexpr int BN = WN * FN * 16;
     static_assert(BM == SCAN_BM, "DB tile must be 256 rows");
     static_assert(WM * WN == NWAVES, "8 waves");
     static_assert(BN % GSLICE_Q == 0, "query block is a whole number of refresh slices");
-    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int OFF_F = NST * STAGE_BYTES;
-    constexpr int PIECES = (BM / 8 + BN / 8) / NWAVES;   // DMA wave-instructions per wave per stage
+    static_assert(NSTB >= 2 && NSTB <= NST, "query ring no deeper than the DB ring");
+    constexpr int A_BYTES = BM * ROW_BYTES;              // one DB stage
+    constexpr int B_BYTES = BN * ROW_BYTES;              // one query stage
+    constexpr int OFF_B = NST * A_BYTES;
+    constexpr int OFF_F = OFF_B + NSTB * B_BYTES;
+    constexpr int PIECES_A = BM / 8 / NWAVES;            // DMA wave-instructions per wave per stage
+    constexpr int PIECES_B = BN / 8 / NWAVES;
+    constexpr int IN_FLIGHT = PIECES_A * (NST - 2) + PIECES_B * (NSTB - 2);   // pieces the end-of-step wait leaves
     static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "every wave issues the same number of pieces");
     using FL = FilterLds<BN>;
     constexpr int PER_WAVE = BN / NWAVES;
@@ -173,15 +181,19 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 
     f32x4 acc[FM][FN];
 
-    // stage index -> (entry, K step) of the stage the DMA cursor points at
-    int d_entry = 0, d_ks = 0;
-    auto issue_stage = [&](int s_idx) {
-        char* buf = smem + (s_idx % NST) * STAGE_BYTES;
-        stage_tile<BM>(dbbase + (size_t)tile_of(d_entry) * BM * ldA + (size_t)kslice(d_ks) * ROW_BYTES, ldA, buf, wave, lane);
-        stage_tile<BN>(qbase + (size_t)kslice(d_ks) * ROW_BYTES, ldB, buf + BM * ROW_BYTES, wave, lane);
+    // stage index -> (entry, K step) of the stage each DMA cursor points at
+    int d_entry = 0, d_ks = 0, q_ks = 0;
+    auto issue_db = [&](int s_idx) {
+        stage_tile<BM>(dbbase + (size_t)tile_of(d_entry) * BM * ldA + (size_t)kslice(d_ks) * ROW_BYTES, ldA,
+                       smem + (s_idx % NST) * A_BYTES, wave, lane);
         if (++d_ks == KS) { d_ks = 0; ++d_entry; }
     };
-    for (int s = 0; s < NST - 1 && s < total_stages; ++s) issue_stage(s);
+    auto issue_q = [&](int s_idx) {
+        stage_tile<BN>(qbase + (size_t)kslice(q_ks) * ROW_BYTES, ldB, smem + OFF_B + (s_idx % NSTB) * B_BYTES, wave, lane);
+        if (++q_ks == KS) q_ks = 0;
+    };
+    for (int s = 0; s < NST - 1 && s < total_stages; ++s) issue_db(s);
+    for (int s = 0; s < NSTB - 1 && s < total_stages; ++s) issue_q(s);
     // The DMA pieces are inline asm, invisible to hipcc: __syncthreads() alone would NOT wait for them (the
     // first K step would read LDS before its tile landed -- harmless-looking in the normal pass, whose first
     // tile only feeds the boot maxima, but rows of the first tile were lost in COLLECT mode).
@@ -194,7 +206,8 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     int refresh_age = 0;           // K steps since it was issued
     int refresh_ctr = 0;
     for (int s = 0; s < total_stages; ++s) {
-        char* cur = smem + (s % NST) * STAGE_BYTES;
+        const char* tA = smem + (s % NST) * A_BYTES;
+        const char* tB = smem + OFF_B + (s % NSTB) * B_BYTES;
         // the bound rows fetched during the previous K step have landed (barrier below)
         // The fetch is younger than the DMA pieces of its own K step, so the counted wait that ends that
         // step leaves it in flight; the wait of the NEXT step retires it (NST = 2 drains everything every step).
@@ -202,10 +215,12 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, lane);
             refresh_pending = -1;
         }
-        // prefetch stage s + NST - 1 into the buffer stage s - 1 used (its readers finished before
-        // the barrier that ended the previous iteration)
+        // prefetch stage s + NST - 1 (queries: s + NSTB - 1) into the buffer stage s - 1 used (its readers
+        // finished before the barrier that ended the previous iteration)
         const bool more = s + NST - 1 < total_stages;
-        if (more) issue_stage(s + NST - 1);
+        if (NSTB < NST && s + NSTB - 1 < total_stages) issue_q(s + NSTB - 1);
+        if (more) issue_db(s + NST - 1);
+        if (NSTB == NST && more) issue_q(s + NSTB - 1);
         {
             // Bound refresh schedule: entry 1 fetches every slice back to back from K step KS/4 on
             // (after every chunk has published its boot maxima); later one slice per tile.
@@ -223,8 +238,6 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const char* tA = cur;
-        const char* tB = cur + BM * ROW_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 a[FM], b[FN];
@@ -270,10 +283,11 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         ++ks;
         if (ks == KS) { ks = 0; ++entry; }
         // stage s + 1 landed (the NST - 2 younger stages stay in flight; anything else this wave issued
-        // in between only makes the wait retire more); everyone done with `cur`; filter state settled
+        // in between only makes the wait retire more); everyone done with this stage; filter state settled
         if (NST == 2 || !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (PIECES * (NST - 2) == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else if (PIECES * (NST - 2) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -288,10 +302,10 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
 }
 
-template <int WM, int WN, int FM, int FN, int NST>
+template <int WM, int WN, int FM, int FN, int NST, int NSTB = NST>
 int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool collect = false) {
     constexpr int BN = WN * FN * 16;
-    constexpr int LDS = NST * (SCAN_BM + BN) * ROW_BYTES + FilterLds<BN>::BYTES;
+    constexpr int LDS = (NST * SCAN_BM + NSTB * BN) * ROW_BYTES + FilterLds<BN>::BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     ScanKernelArgs k = make_kernel_args(plan, a);
     if (collect) {
@@ -299,7 +313,7 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool
         k.unc_count = a.unc_count;
         k.collect_lo = a.collect_lo; k.collect_hi = a.collect_hi;
     }
-    auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true, NST> : scan_bf16_kernel<WM, WN, FM, FN, false, NST>;
+    auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true, NST, NSTB> : scan_bf16_kernel<WM, WN, FM, FN, false, NST, NSTB>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[collect]) {
         SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -357,11 +371,18 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     return p;
 }
 
+// SQE_SCAN128=2: the older two-stage ring of the 128-query tile (A/B comparisons)
+static bool bn128_two_stage() {
+    static const bool v = [] { const char* e = getenv("SQE_SCAN128"); return e && e[0] == '2'; }();
+    return v;
+}
+
 int launch_scan_collect(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (!a.collect_thr || !a.collect_keys || !a.collect_cnt || !a.unc_count)
         return fail(SQE_ERR_INVALID, "scan collect: missing buffers");
     if (plan.bn == 256) return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream, true);
-    if (plan.bn == 128) return launch_cfg<4, 2, 4, 4, 2>(plan, a, stream, true);
+    if (plan.bn == 128) return bn128_two_stage() ? launch_cfg<4, 2, 4, 4, 2>(plan, a, stream, true)
+                                                 : launch_cfg<4, 2, 4, 4, 3, 2>(plan, a, stream, true);
     return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream, true);
 }
 
@@ -383,7 +404,8 @@ int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream
         if (which == 2) return launch_scan_bf16_pp(plan, a, stream);
         return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream);
     }
-    if (plan.bn == 128) return launch_cfg<4, 2, 4, 4, 2>(plan, a, stream);
+    if (plan.bn == 128) return bn128_two_stage() ? launch_cfg<4, 2, 4, 4, 2>(plan, a, stream)
+                                                 : launch_cfg<4, 2, 4, 4, 3, 2>(plan, a, stream);
     return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream);
 }
 
