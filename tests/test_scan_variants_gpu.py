@@ -20,7 +20,7 @@ from oracle import retrieval as R
 from semantic_query_engine_amd import Context, VectorIndex
 from tests.gpu_util import assert_topk_matches, exact_topk_fast
 rng = np.random.default_rng(4)
-n, d, b, k = 300000, 256, 300, 10
+n, d, b, k = 300000, 256, %(batch)d, 10
 x = rng.standard_normal((n, d)).astype(np.float32)
 q = rng.standard_normal((b, d)).astype(np.float32)
 q[:50] = x[rng.integers(0, n, 50)] + 0.1 * q[:50]
@@ -37,6 +37,16 @@ print(json.dumps({"ok": True, "uncertified": int(ctx.stats()["uncertified"])}))
 @pytest.mark.parametrize("which", ["v0", "p8", "pp"])
 def test_alternative_scan_kernels(which):
     env = dict(os.environ, SQE_SCAN=which)
-    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "batch": 300}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
+
+
+@pytest.mark.parametrize("ring", ["2", "3"])
+def test_128_query_tile_ring_depths(ring):
+    """Batches of 65-128 run on the 128-query tile: the two-stage ring (SQE_SCAN128=2) and the default
+    (DB stages three deep, query stages two deep) both return the oracle's answer."""
+    env = dict(os.environ, SQE_SCAN128=ring)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "batch": 100}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
