@@ -506,6 +506,113 @@ int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_st
     return SQE_OK;
 }
 
+// A handful of tokens (T <= 64: one query, as the reference issues it): every GEMM of the layer is a few MB of
+// weights against at most four 16-token groups, i.e. one memory round trip if the whole chip pulls on it at once,
+// and the 128-row tiles above give it 8-32 workgroups.  Here a workgroup owns 16 output features: its 4 waves
+// split K, each lane reads its MFMA fragments straight from global memory (W row n0 + (lane & 15), 16 B at
+// k + 32 i + 8 (lane >> 4): 64 contiguous bytes per row per instruction; X rows the same way, L2-resident), no
+// LDS staging, the four partial sums meet in LDS and wave j finishes token group j.  N / 16 workgroups (x the
+// split-K factor for the two N = hidden GEMMs, whose partial sums the LayerNorm kernels already add).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+    __shared__ float4 red[4][4][64];          // [K-split wave][token group][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int groups = p.N >> 4;
+    const int split = blockIdx.x / groups;
+    const int n0 = (blockIdx.x % groups) << 4;
+    const int nt = (p.T + 15) >> 4;           // 16-token groups, <= 4
+    const int kwave = p.K / p.splits / 4;     // K elements per wave, a multiple of 128
+    const int kbeg = split * (p.K / p.splits) + wave * kwave;
+    const int r = lane & 15, c = lane >> 4;
+    const bf16_t* wrow = p.W + (size_t)(n0 + r) * p.K + kbeg + c * 8;
+    const bf16_t* xrow = p.X + (size_t)r * p.K + kbeg + c * 8;
+    const size_t xgroup = (size_t)16 * p.K;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // two 128-wide steps per pass, the loads of both issued before the first MFMA (kwave is 128 or 256 for the
+    // BERT-large shapes: one pass, one memory round trip)
+    for (int k = 0; k < kwave; k += 256) {
+        bf16x8 a[2][4], b[2][4][4];
+        const bool two = k + 128 < kwave;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h == 0 || two) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[h][i] = *reinterpret_cast<const bf16x8*>(wrow + k + h * 128 + i * 32);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nt) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            b[h][j][i] = *reinterpret_cast<const bf16x8*>(xrow + j * xgroup + k + h * 128 + i * 32);
+                    }
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h == 0 || two) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nt) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h][i], b[h][j][i], acc[j], 0, 0, 0);
+                    }
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nt) red[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    __syncthreads();
+    if (wave >= nt) return;
+    // wave j: token group j, partial sums added in wave order (deterministic)
+    const int j = wave;
+    float4 v = red[0][j][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 u = red[w][j][lane];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int t = j * 16 + r;
+    if (t >= p.T) return;
+    const int n = n0 + c * 4;
+    if (!(EPI == EPI_RESID && split != 0)) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    }
+    const size_t o = (size_t)t * p.N + n;
+    if (EPI == EPI_RESID) {
+        if (split == 0) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o);
+            v.x += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v.y += bf16_to_f32((bf16_t)(r2.x >> 16));
+            v.z += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v.w += bf16_to_f32((bf16_t)(r2.y >> 16));
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)split * p.split_stride + o) = v;
+    } else {
+        if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        uint2 w2;
+        w2.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        w2.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
+    }
+}
+
+template <int EPI>
+int launch_gemm_skinny(const GemmArgs& a, int cu_count, size_t split_stride, int* splits_out, hipStream_t stream) {
+    GemmArgs p = a;
+    int splits = 1;
+    if (EPI == EPI_RESID)
+        while (splits < 4 && a.K % (512 * splits * 2) == 0 && (a.N / 16) * splits * 2 <= cu_count) splits *= 2;
+    p.splits = splits;
+    p.split_stride = split_stride;
+    if (splits_out) *splits_out = splits;
+    hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3((a.N / 16) * splits), dim3(256), 0, stream, p);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
 // 256x256 tiles when there are enough tokens to fill the chip with them, the 128x128 ring kernel otherwise.
 // *splits_out = number of fp32 partial sums written (EPI_RESID), `split_stride` floats apart.
 template <int EPI>
@@ -513,6 +620,10 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
                 int* splits_out = nullptr) {
     if (a.N % 128 != 0 || a.K % 64 != 0) return fail(SQE_ERR_INVALID, "encoder gemm: N % 128 or K % 64");
     if (splits_out) *splits_out = 1;
+    if (EPI != EPI_F32 && a.T <= 64 && a.K % 512 == 0) {
+        static const bool off = [] { const char* e = getenv("SQE_ENC_SKINNY"); return e && e[0] == '0'; }();
+        if (!off) return launch_gemm_skinny<EPI>(a, cu_count, split_stride, splits_out, stream);
+    }
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
     if (big) {
         static const bool old_form = [] { const char* e = getenv("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
