@@ -671,6 +671,31 @@ __device__ __forceinline__ void ln_stats(const float* row, int H, int lane, floa
     rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
 }
 
+// Rows of at most 1024 elements (H % 256 == 0) are read ONCE into registers -- one memory round trip instead of
+// three; sums run in the order ln_stats uses, so both forms give the same bits.
+__device__ __forceinline__ bool ln_row_regs(const float* row, int H, int lane, float eps, int nsplit, size_t stride,
+                                            float4 (&v)[4], float& mean, float& rstd) {
+    const int nit = H >> 8;
+    if ((H & 255) != 0 || nit > 4) return false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (it < nit) v[it] = ln_load(row, lane * 4 + it * 256, nsplit, stride);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (it < nit) s += v[it].x + v[it].y + v[it].z + v[it].w;
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (it < nit) {
+            const float a = v[it].x - mean, b = v[it].y - mean, c = v[it].z - mean, d = v[it].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ g,
                                                         const float* __restrict__ b, bf16_t* __restrict__ out,
                                                         int T, int H, float eps, int nsplit, size_t stride) {
@@ -679,6 +704,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= T) return;
     const float* x = in + (size_t)row * H;
     float mean, rstd;
+    float4 vr[4];
+    if (ln_row_regs(x, H, lane, eps, nsplit, stride, vr, mean, rstd)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (it < (H >> 8)) {
+                const int i = lane * 4 + it * 256;
+                const float4 v = vr[it];
+                const float4 gg = *reinterpret_cast<const float4*>(g + i);
+                const float4 bb = *reinterpret_cast<const float4*>(b + i);
+                uint2 w;
+                w.x = (uint32_t)f32_to_bf16((v.x - mean) * rstd * gg.x + bb.x) | ((uint32_t)f32_to_bf16((v.y - mean) * rstd * gg.y + bb.y) << 16);
+                w.y = (uint32_t)f32_to_bf16((v.z - mean) * rstd * gg.z + bb.z) | ((uint32_t)f32_to_bf16((v.w - mean) * rstd * gg.w + bb.w) << 16);
+                *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = w;
+            }
+        return;
+    }
     ln_stats(x, H, lane, mean, rstd, eps, nsplit, stride);
     for (int i = lane * 4; i < H; i += 256) {
         const float4 v = ln_load(x, i, nsplit, stride);
@@ -700,6 +741,21 @@ __global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ 
     if (seq >= B) return;
     const float* x = in + (size_t)seq * S * H;
     float mean, rstd;
+    float4 vr[4];
+    if (ln_row_regs(x, H, lane, eps, nsplit, stride, vr, mean, rstd)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (it < (H >> 8)) {
+                const int i = lane * 4 + it * 256;
+                const float4 v = vr[it];
+                const float4 gg = *reinterpret_cast<const float4*>(g + i);
+                const float4 bb = *reinterpret_cast<const float4*>(b + i);
+                *reinterpret_cast<float4*>(out + (size_t)seq * H + i) =
+                    make_float4((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
+                                (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+            }
+        return;
+    }
     ln_stats(x, H, lane, mean, rstd, eps, nsplit, stride);
     for (int i = lane * 4; i < H; i += 256) {
         const float4 v = ln_load(x, i, nsplit, stride);
