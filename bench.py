@@ -75,14 +75,15 @@ def library_gemm_tflops(b: int, device) -> float:
 def committed_traffic(rows: int, b: int) -> "float | None":
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (tools/pmc_scan.sh ->
     profiles/r01_search/pmc_traffic.json), if they were taken on this workload; else None."""
-    path = os.path.join(ROOT, "profiles", "r01_search", "pmc_traffic.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if t.get("rows") != rows or t.get("batch") != b:
-        return None
-    return float(t["hbm_bytes_per_launch"])
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_search", "pmc_traffic*.json"))):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if t.get("rows") == rows and t.get("batch") == b:
+            return float(t["hbm_bytes_per_launch"])
+    return None
 
 
 def cpu_baseline_hnsw(rows: int, b: int, k: int) -> dict:
