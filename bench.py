@@ -8,7 +8,8 @@ One "step" = one pass of the hot path over one batch of B synthetic queries that
 already resident in HBM: sqe_index_search_device (query normalise + bf16 MFMA scan with
 fused top-k filter + fp32 rescore) and, for N > 1, the all-gather of per-shard top-k over
 RCCL plus the merge kernel.  The 10M-row index is sharded row-wise across the N ranks
-(strong scaling: the job is "answer B queries over the 10M-row index").
+(strong scaling: the job is "answer B queries over the 10M-row index"; `--rows-per-gpu R` is the weak form of
+BASELINE.json's config 4, R rows on every rank, e.g. 8 x 10M = 80M rows).
 
 Rank 0 prints ONE JSON line (see the task contract); `roofline` is for the scan kernel
 (hipEvent-timed inside libsqe on the stream it runs on), `cpu_baseline` is the NumPy
@@ -187,6 +188,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (all ranks)")
+    ap.add_argument("--rows-per-gpu", type=int, default=0,
+                    help="config 4 of BASELINE.json (weak scaling): every rank holds this many rows, the index is "
+                         "N x as large (e.g. 10000000 -> 80M rows on 8 GPUs); overrides --rows")
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,6 +221,8 @@ def main():
     from semantic_query_engine_amd.sharded import ShardedSearcher
 
     ctx = Context(local_rank)
+    if args.rows_per_gpu > 0:
+        args.rows = args.rows_per_gpu * world
     n_total, b, k = args.rows, args.batch, args.k
     rows_per = (n_total + world - 1) // world
     row_lo, row_hi = rank * rows_per, min(n_total, (rank + 1) * rows_per)
@@ -327,10 +333,12 @@ def main():
             roof["library_gemm_tflops"] = round(lib, 1)
             roof["frac_of_library_gemm"] = round(tflops / lib, 4)
         out = {
-            "metric": "k-NN queries/sec (brute-force cosine top-10, 1024-d, 10M vectors)",
+            "metric": f"k-NN queries/sec (brute-force cosine top-{k}, 1024-d, "
+                      f"{n_total // 1_000_000}M vectors)" if n_total % 1_000_000 == 0 else
+                      f"k-NN queries/sec (brute-force cosine top-{k}, 1024-d, {n_total} vectors)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak" if args.rows_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"flat cosine top-{k}, N={n_total} x {D} fp32 (bf16 scan + fp32 rescore), "
                                    f"batch={b} queries/step, index row-sharded over {world} GPU(s)",
                        "rows": n_total, "dim": D, "batch": b, "k": k, "parallelism": f"shard{world}"},
