@@ -5,11 +5,29 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 
 #include "sqe.h"
 
 namespace sqe {
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: a process that opens contexts on two
+// GPUs needs it once per (kernel, device), not once per process.
+inline hipError_t ensure_dynamic_lds(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({kern, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kern, dev});
+    return e;
+}
+
 
 // ---------------------------------------------------------------- error plumbing
 void set_error(const std::string& msg);

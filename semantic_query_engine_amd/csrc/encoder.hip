@@ -194,11 +194,7 @@ int launch_gemm_cfg(const GemmArgs& a, int t_pad, hipStream_t stream) {
     GemmArgs p = a;
     p.n_tiles = a.N / BNW;
     auto kern = gemm_bf16_kernel<FM, FN, EPI>;
-    static bool attr = false;
-    if (!attr) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3(p.n_tiles * (t_pad / BT)), dim3(512), LDS, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
@@ -357,11 +353,7 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
     p.splits = 1; p.split_stride = 0;
     const int tiles = p.n_tiles * p.t_tiles;
     auto kern = gemm_persistent_kernel<EPI>;
-    static bool attr = false;
-    if (!attr) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count)), dim3(512), LDS, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
@@ -496,11 +488,7 @@ int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_st
     p.split_stride = split_stride;
     if (splits_out) *splits_out = splits;
     auto kern = gemm_ring_kernel<EPI>;
-    static bool attr = false;
-    if (!attr) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), LDS, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;

@@ -696,12 +696,7 @@ static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev,
         SQE_TRY(launch_normalize_rows(index_master(st->coarse), nlist, dim, nullptr, st->cent_bf16.as<bf16_t>(), dim, nullptr, nullptr, s));
         st->cent_dirty = false;
     }
-    static bool attr = false;
-    if (!attr) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_probe_select_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_probe_select_kernel), 64 * 1024));
     const int64_t step = 16384;
     const int64_t cap = std::min(step, (b + 127) / 128 * 128);
     SQE_TRY(st->qd.ensure((size_t)cap * dim * 2));
@@ -886,12 +881,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>());
     } else {
-        static bool attr = false;
-        if (!attr) {
-            SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS));
-            attr = true;
-        }
+        SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel), LS_LDS));
         hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, index_scan(base), pitch, st->qb.as<bf16_t>(),
                            pitch, st->order.as<int>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe,
                            dim, max_len, st->pair_scores.as<float>());

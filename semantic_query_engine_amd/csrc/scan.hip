@@ -314,12 +314,7 @@ int launch_cfg(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream, bool
         k.collect_lo = a.collect_lo; k.collect_hi = a.collect_hi;
     }
     auto kern = collect ? scan_bf16_kernel<WM, WN, FM, FN, true, NST, NSTB> : scan_bf16_kernel<WM, WN, FM, FN, false, NST, NSTB>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[collect]) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set[collect] = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(THREADS), LDS, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;

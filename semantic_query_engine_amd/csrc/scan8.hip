@@ -534,11 +534,7 @@ int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& a, hipStream_t str
     ScanKernelArgs k = make_kernel_args(plan, a);
     static const int slots = [] { const char* e = getenv("SQE_P8_SLOTS"); return e && e[0] == '4' ? 4 : 2; }();
     auto kern = slots == 2 ? scan_bf16_p8_kernel<2> : scan_bf16_p8_kernel<4>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;

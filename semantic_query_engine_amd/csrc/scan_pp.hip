@@ -508,11 +508,7 @@ int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& a, hipStream_t str
     static const bool syncf = [] { const char* e = getenv("SQE_PP_SYNCF"); return !(e && e[0] == '0'); }();
     auto kern = syncf ? (split ? scan_bf16_pp_kernel<true, true> : scan_bf16_pp_kernel<false, true>)
                       : (split ? scan_bf16_pp_kernel<true, false> : scan_bf16_pp_kernel<false, false>);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;

@@ -263,12 +263,7 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
     k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max; k.unc_count = a.unc_count; k.collect_thr = a.collect_thr;
     if ((int64_t)a.n_chunks * a.kp > 4096) {              // few query blocks, many chunks: B <= 256
         constexpr int LDS = 16384 * 8;
-        static bool attr = false;
-        if (!attr) {
-            SQE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_rescore_kernel<1024, 16384>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr = true;
-        }
+        SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(select_rescore_kernel<1024, 16384>), LDS));
         hipLaunchKernelGGL((select_rescore_kernel<1024, 16384>), dim3(a.B), dim3(1024), LDS, stream, k);
     } else {
         hipLaunchKernelGGL((select_rescore_kernel<256, 4096>), dim3(a.B), dim3(256), 4096 * 8, stream, k);
