@@ -35,11 +35,14 @@ struct SelectKernelArgs {
 // Returns 0 when there are fewer than kth keys (everything qualifies).
 template <int SEL_THREADS, typename Get>
 __device__ uint64_t block_select_kth(Get get, int n, int kth, int* hist, int* scratch) {
+    static_assert(SEL_THREADS >= 256, "one thread per histogram bin");
+    __shared__ int wave_total[4];
     const int tid = threadIdx.x;
     uint64_t prefix = 0;      // determined high bytes
     int remaining = kth;
     for (int byte = 7; byte >= 0; --byte) {
         if (tid < 256) hist[tid] = 0;
+        if (tid == 0) scratch[0] = -1;     // stays -1 when there are fewer than `remaining` keys in total
         __syncthreads();
         const int shift = byte * 8;
         for (int e = tid; e < n; e += SEL_THREADS) {
@@ -49,14 +52,30 @@ __device__ uint64_t block_select_kth(Get get, int n, int kth, int* hist, int* sc
             if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 255;
-            for (; bin >= 0; --bin) {
-                if (cum + hist[bin] >= remaining) break;
-                cum += hist[bin];
+        // the bin holding the `remaining`-th largest key: thread b owns bin b; keys in higher bins are counted by
+        // a suffix scan (shuffles inside a wave, four wave totals through LDS) instead of one thread walking
+        // down from bin 255 -- that walk was most of this kernel's time
+        int h = 0, incl = 0;
+        if (tid < 256) {
+            const int ln = tid & 63;
+            h = hist[tid];
+            incl = h;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_down(incl, off, 64);
+                if (ln + off < 64) incl += v;
             }
-            scratch[0] = bin;          // -1: fewer than `remaining` keys in total
-            scratch[1] = remaining - cum;
+            if (ln == 0) wave_total[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            int above = 0;
+            for (int w = (tid >> 6) + 1; w < 4; ++w) above += wave_total[w];
+            const int excl = above + incl - h;          // keys in bins above this one
+            if (excl < remaining && excl + h >= remaining) {
+                scratch[0] = tid;
+                scratch[1] = remaining - excl;
+            }
         }
         __syncthreads();
         const int bin = scratch[0];
