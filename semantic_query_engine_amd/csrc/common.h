@@ -112,4 +112,42 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Radix-select step shared by the select kernels: hist[256] is complete (caller synchronised) and every thread
+// of the block (>= 256 threads) calls.  Finds the bin that holds the `remaining`-th largest entry counting down
+// from bin 255: bin (or -1 when the histogram holds fewer than `remaining` entries) and what is left to find
+// inside it.  One thread per bin and a suffix scan (shuffles inside a wave, four wave totals through LDS)
+// instead of one thread walking down from bin 255.
+__device__ __forceinline__ void hist_locate(const int* hist, int remaining, int& bin, int& rem) {
+    __shared__ int s_wave_total[4];
+    __shared__ int s_found[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_found[0] = -1;
+    int h = 0, incl = 0;
+    if (tid < 256) {
+        const int ln = tid & 63;
+        h = hist[tid];
+        incl = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_down(incl, off, 64);
+            if (ln + off < 64) incl += v;
+        }
+        if (ln == 0) s_wave_total[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int above = 0;
+        for (int w = (tid >> 6) + 1; w < 4; ++w) above += s_wave_total[w];
+        const int excl = above + incl - h;          // entries in the bins above this one
+        if (excl < remaining && excl + h >= remaining) {
+            s_found[0] = tid;
+            s_found[1] = remaining - excl;
+        }
+    }
+    __syncthreads();
+    bin = s_found[0];
+    rem = bin < 0 ? remaining : s_found[1];
+    __syncthreads();                                // the next call resets s_found
+}
+
 }  // namespace sqe

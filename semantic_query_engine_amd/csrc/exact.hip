@@ -67,14 +67,10 @@ __global__ __launch_bounds__(256) void collect_rescore_kernel(RescoreArgs p) {
             if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 255;
-            for (; bin >= 0; --bin) {
-                if (cum + hist[bin] >= remaining) break;
-                cum += hist[bin];
-            }
-            scratch[0] = bin < 0 ? 0 : bin;
-            scratch[1] = bin < 0 ? remaining : remaining - cum;
+        {
+            int hb, hr;
+            hist_locate(hist, remaining, hb, hr);
+            if (tid == 0) { scratch[0] = hb < 0 ? 0 : hb; scratch[1] = hr; }
         }
         __syncthreads();
         prefix |= ((uint64_t)scratch[0] << shift);

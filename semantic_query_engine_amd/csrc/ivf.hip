@@ -160,14 +160,10 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
             if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 255;
-            for (; bin >= 0; --bin) {
-                if (cum + hist[bin] >= remaining) break;
-                cum += hist[bin];
-            }
-            scratch[0] = bin < 0 ? 0 : bin;
-            scratch[1] = bin < 0 ? remaining : remaining - cum;
+        {
+            int hb, hr;
+            hist_locate(hist, remaining, hb, hr);
+            if (tid == 0) { scratch[0] = hb < 0 ? 0 : hb; scratch[1] = hr; }
         }
         __syncthreads();
         prefix |= ((uint64_t)scratch[0] << shift);
@@ -525,14 +521,10 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
                     if (byte == 3 || (v32 >> (shift + 8)) == (pre >> (shift + 8))) atomicAdd(&hist[(v32 >> shift) & 0xff], 1);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int cum = 0, bin = 255;
-                    for (; bin >= 0; --bin) {
-                        if (cum + hist[bin] >= rem) break;
-                        cum += hist[bin];
-                    }
-                    scratch[1] = bin < 0 ? 0 : bin;
-                    scratch[3] = bin < 0 ? rem : rem - cum;
+                {
+                    int hb, hr;
+                    hist_locate(hist, rem, hb, hr);
+                    if (tid == 0) { scratch[1] = hb < 0 ? 0 : hb; scratch[3] = hr; }
                 }
                 __syncthreads();
                 pre |= ((uint32_t)scratch[1] << shift);
@@ -592,14 +584,10 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 255;
-            for (; bin >= 0; --bin) {
-                if (cum + hist[bin] >= remaining) break;
-                cum += hist[bin];
-            }
-            scratch[0] = bin < 0 ? 0 : bin;
-            scratch[1] = bin < 0 ? remaining : remaining - cum;
+        {
+            int hb, hr;
+            hist_locate(hist, remaining, hb, hr);
+            if (tid == 0) { scratch[0] = hb < 0 ? 0 : hb; scratch[1] = hr; }
         }
         __syncthreads();
         prefix |= ((uint64_t)scratch[0] << shift);
