@@ -35,14 +35,12 @@ struct SelectKernelArgs {
 // Returns 0 when there are fewer than kth keys (everything qualifies).
 template <int SEL_THREADS, typename Get>
 __device__ uint64_t block_select_kth(Get get, int n, int kth, int* hist, int* scratch) {
-    static_assert(SEL_THREADS >= 256, "one thread per histogram bin");
-    __shared__ int wave_total[4];
+    static_assert(SEL_THREADS >= 256, "hist_locate: one thread per histogram bin");
     const int tid = threadIdx.x;
     uint64_t prefix = 0;      // determined high bytes
     int remaining = kth;
     for (int byte = 7; byte >= 0; --byte) {
         if (tid < 256) hist[tid] = 0;
-        if (tid == 0) scratch[0] = -1;     // stays -1 when there are fewer than `remaining` keys in total
         __syncthreads();
         const int shift = byte * 8;
         for (int e = tid; e < n; e += SEL_THREADS) {
@@ -52,37 +50,11 @@ __device__ uint64_t block_select_kth(Get get, int n, int kth, int* hist, int* sc
             if (match) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
         }
         __syncthreads();
-        // the bin holding the `remaining`-th largest key: thread b owns bin b; keys in higher bins are counted by
-        // a suffix scan (shuffles inside a wave, four wave totals through LDS) instead of one thread walking
-        // down from bin 255 -- that walk was most of this kernel's time
-        int h = 0, incl = 0;
-        if (tid < 256) {
-            const int ln = tid & 63;
-            h = hist[tid];
-            incl = h;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_down(incl, off, 64);
-                if (ln + off < 64) incl += v;
-            }
-            if (ln == 0) wave_total[tid >> 6] = incl;
-        }
-        __syncthreads();
-        if (tid < 256) {
-            int above = 0;
-            for (int w = (tid >> 6) + 1; w < 4; ++w) above += wave_total[w];
-            const int excl = above + incl - h;          // keys in bins above this one
-            if (excl < remaining && excl + h >= remaining) {
-                scratch[0] = tid;
-                scratch[1] = remaining - excl;
-            }
-        }
-        __syncthreads();
-        const int bin = scratch[0];
-        if (bin < 0) return 0ull;
+        int bin, rem;
+        hist_locate(hist, remaining, bin, rem);      // ends with a barrier: hist may be cleared again
+        if (bin < 0) return 0ull;                    // fewer than `remaining` keys in total
         prefix |= ((uint64_t)bin << shift);
-        remaining = scratch[1];
-        __syncthreads();
+        remaining = rem;
     }
     return prefix;
 }
