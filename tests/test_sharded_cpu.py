@@ -72,14 +72,15 @@ def _data():
     return x, q
 
 
-def _worker(rank, world, port, k, out):
+def _worker(rank, world, port, k, out, force=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     x, q = _data()
     lo, hi = shard_rows(x.shape[0], world, rank)
     s = ShardedSearcher(OracleCtx(), OracleShardIndex(x[lo:hi]), id_base=lo, dist=dist, world=world,
-                        device=torch.device("cpu"))
+                        device=torch.device("cpu"), force_collective=force)
+    assert s.collective == (world > 1 or force)
     cos, ids = s.search(torch.from_numpy(q), k)
     s.synchronize()
     if rank == 0:
@@ -112,6 +113,21 @@ def test_sharded_search_matches_global_oracle(world, k):
     valid = ref_ids >= 0
     assert np.allclose(cos[valid], ref_cos[valid], atol=1e-6) and np.all(np.isneginf(cos[~valid]))
     assert ids[0, :3].tolist() == [7, 151, 250]          # equal cosines across shards: lowest id first
+
+
+def test_one_rank_forced_collective_path():
+    """The rehearsal form used on a one-GPU box (bench.py --force-collective): a one-rank group still goes
+    through pack -> all-gather -> merge and returns the global answer."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), 10, out, True))
+    p.start()
+    cos, ids = out.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    x, q = _data()
+    ref_cos, ref_ids = R.knn_search(x, q, 10)
+    assert np.array_equal(ids, ref_ids) and np.allclose(cos, ref_cos, atol=1e-6)
 
 
 def test_shard_rows_and_message_layout():
