@@ -14,7 +14,8 @@
 //     the others while they run in step.
 //
 // This file holds the generic staged form (one barrier per 64-wide K step; LDS ring of 2 stages for the
-// 256- and 128-query tiles, 3 for the HBM-bound 64-query tile): the kernel of batches <= 128 and of the
+// 256-query tile, 3 for the HBM-bound 64-query tile, DB stages 3 deep and query stages 2 deep for the
+// 128-query tile -- what fits in 160 KiB): the kernel of batches <= 128 and of the
 // collect pass, and the A/B baseline for 256-query blocks, whose default is the ping-pong schedule of
 // scan_pp.hip (scan8.hip holds a third schedule).  Both operand tiles go global -> LDS in full 128-B
 // lines; the XOR chunk swizzle c' = c ^ ((row >> 1) & 7) is applied on the per-lane SOURCE
