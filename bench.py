@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work: started WITHOUT a torch.distributed environment and with --gpus N > 1, this script starts
+its own N rank processes (a child `python -m torch.distributed.run`, before anything touches the GPU),
+relays rank 0's JSON line and exits with the children's code.
+
 One "step" = one pass of the hot path over one batch of B synthetic queries that are
 already resident in HBM: sqe_index_search_device (query normalise + bf16 MFMA scan with
 fused top-k filter + fp32 rescore) and, for N > 1, the all-gather of per-shard top-k over
@@ -73,18 +77,36 @@ def library_gemm_tflops(b: int, device) -> float:
     return 2.0 * b * n * D / ms / 1e9
 
 
-def committed_traffic(rows: int, b: int) -> "float | None":
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (tools/pmc_scan.sh ->
-    profiles/r01_search/pmc_traffic.json), if they were taken on this workload; else None."""
+def scan_source_hash() -> str:
+    """sha256 over the sources of the scan kernels: a PMC traffic figure is only quoted for the kernel it was
+    measured on (tools/pmc_scan.sh records the same hash next to the bytes)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "semantic_query_engine_amd", "csrc")
+    for name in ("common.h", "kernels.h", "scan_common.h", "scan.hip", "scan_pp.hip"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(rows: int, b: int):
+    """(HBM bytes per scan launch, source file) from the committed rocprofv3 PMC passes (tools/pmc_scan.sh ->
+    profiles/r*/pmc_traffic*.json) taken on this workload AND on the scan kernel sources of this tree;
+    (None, reason) otherwise.  The figure is read from a committed file, not measured in this run."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_search", "pmc_traffic*.json"))):
+    want = scan_source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")), reverse=True):
         try:
             t = json.load(open(path))
         except (OSError, ValueError):
             continue
         if t.get("rows") == rows and t.get("batch") == b:
-            return float(t["hbm_bytes_per_launch"])
-    return None
+            rel = os.path.relpath(path, ROOT)
+            if t.get("scan_src_sha") == want:
+                return float(t["hbm_bytes_per_launch"]), rel
+            stale = stale or f"{rel} was measured on other scan sources ({t.get('scan_src_sha')} != {want})"
+    return None, stale or "no committed PMC pass for this workload"
 
 
 def cpu_baseline_hnsw(rows: int, b: int, k: int) -> dict:
@@ -182,6 +204,54 @@ def exact_reference(q: torch.Tensor, n_total: int, row_lo: int, row_hi: int, k: 
     return best_s, best_i
 
 
+def self_launch(n: int, argv) -> "int":
+    """`python bench.py --gpus N` with no rank environment: run the N ranks as a CHILD torch.distributed.run
+    (never an exec of this process), stdout/stderr inherited so rank 0's JSON line is this process's line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd).returncode
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """--dry: the launch plumbing only, on CPU (gloo): rank environment, process group, barrier-bracketed
+    timed region, MAX over ranks, ONE JSON line from rank 0.  No GPU, no search: `value` is null.  The N > 1
+    data path itself is covered by tests/test_sharded_cpu.py."""
+    import torch.distributed as dist
+    if world > 1 or "MASTER_ADDR" in os.environ:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist = None
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))                      # uneven ranks: the MAX must be the slowest one's
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        rows = args.rows_per_gpu * world if args.rows_per_gpu > 0 else args.rows
+        print(json.dumps({"metric": "k-NN queries/sec (dry run: launch plumbing only)", "value": None, "unit": "queries/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak" if args.rows_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "bf16",
+                          "data": "none", "dry": True,
+                          "config": {"workload": "dry run", "rows": rows, "batch": args.batch, "parallelism": f"shard{world}"}}),
+              flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,14 +271,20 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal on a one-GPU box: launched through torch.distributed.run with ONE rank, take the "
                          "all-gather + merge path of the N > 1 search anyway")
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU rehearsal of the launch plumbing (gloo, no GPU, no search): see dry_run()")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nothing has touched the GPU yet (importing torch does not): start the ranks as children
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -323,11 +399,11 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None}
-        roof.update({"kernel": "scan_bf16_pp_kernel" if os.environ.get("SQE_SCAN", "pp").startswith("pp") and b > 128 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
+        roof.update({"kernel": "scan_bf16_pp_kernel" if b > 128 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                      "hbm_gbps": round(gbps, 1), "mfma_tflops": round(tflops, 2)})
         if world == 1:
-            roof["traffic"] = committed_traffic(n_total, b)
+            roof["traffic"], roof["traffic_source"] = committed_traffic(n_total, b)
         if roof["bound"] == "mfma" and world == 1 and not args.no_gemm_ref:
             lib = library_gemm_tflops(b, device)
             roof["library_gemm_tflops"] = round(lib, 1)

@@ -349,7 +349,7 @@ int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out
     {
         // rows of the scanned copy are padded by one 128-B line by default: with a 2^n pitch every
         // row of a K slice would sit in the same memory channel
-        const char* e = getenv("SQE_ROW_PAD");
+        const char* e = knob_env("SQE_ROW_PAD");
         const int pad = e ? atoi(e) : 128;
         idx->pitch = dim * 2 + (pad >= 0 && pad % 8 == 0 ? pad : 128);
     }
@@ -559,7 +559,7 @@ int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, in
         a.dbg_counters = nullptr;
         a.collect_thr = nullptr; a.collect_keys = nullptr; a.collect_cnt = nullptr; a.unc_count = nullptr;
         {
-            static const bool want = [] { const char* e = getenv("SQE_DBG"); return e && (atoi(e) & 32); }();
+            static const bool want = [] { const char* e = knob_env("SQE_DBG"); return e && (atoi(e) & 32); }();
             if (want) {
                 SQE_TRY(idx->dbg.ensure(64));
                 SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 64, c->stream));

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <set>
@@ -28,6 +29,18 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int bytes) {
     return e;
 }
 
+
+// Experiment / schedule knobs (SQE_DBG, SQE_SCAN, SQE_KROT, ...) exist only in -DSQE_DEBUG_KNOBS builds
+// (make KNOBS=1 -> libsqe_knobs.so, used by tools/ and the schedule-variant tests).  The shipped library
+// reads NO environment variable: nothing outside the ABI can change what a search returns.
+inline const char* knob_env(const char* name) {
+#ifdef SQE_DEBUG_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---------------------------------------------------------------- error plumbing
 void set_error(const std::string& msg);

@@ -609,12 +609,12 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
     if (a.N % 128 != 0 || a.K % 64 != 0) return fail(SQE_ERR_INVALID, "encoder gemm: N % 128 or K % 64");
     if (splits_out) *splits_out = 1;
     if (EPI != EPI_F32 && a.T <= 64 && a.K % 512 == 0) {
-        static const bool off = [] { const char* e = getenv("SQE_ENC_SKINNY"); return e && e[0] == '0'; }();
+        static const bool off = [] { const char* e = knob_env("SQE_ENC_SKINNY"); return e && e[0] == '0'; }();
         if (!off) return launch_gemm_skinny<EPI>(a, cu_count, split_stride, splits_out, stream);
     }
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
     if (big) {
-        static const bool old_form = [] { const char* e = getenv("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
+        static const bool old_form = [] { const char* e = knob_env("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
         if (!old_form) return launch_gemm_persistent<EPI>(a, t_pad, cu_count, stream);
         GemmArgs p = a;
         p.splits = 1; p.split_stride = 0; p.t_tiles = 0;
@@ -1056,7 +1056,7 @@ int sqe_encoder_create(sqe_ctx* ctx, const sqe_bert_cfg* cfg, sqe_encoder** out)
     e->cfg = *cfg;
     for (int l = 0; l < cfg->layers; ++l) e->layers.emplace_back(new sqe_layer);
     {
-        const char* g = getenv("SQE_ENC_GRAPH");          // SQE_ENC_GRAPH=0: always launch kernel by kernel
+        const char* g = knob_env("SQE_ENC_GRAPH");          // SQE_ENC_GRAPH=0: always launch kernel by kernel
         e->use_graphs = !(g && g[0] == '0');
     }
     *out = e.release();

@@ -863,7 +863,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
                        st->lcount.as<int>(), st->lq.as<int>(), B);
     // S6: list scan
-    static const bool fp32_lists = [] { const char* e = getenv("SQE_IVF_FP32"); return e && e[0] == '1'; }();
+    static const bool fp32_lists = [] { const char* e = knob_env("SQE_IVF_FP32"); return e && e[0] == '1'; }();
     if (fp32_lists) {
         hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, index_master(base), st->qn.as<float>(), st->order.as<int>(),
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,

@@ -62,11 +62,8 @@ struct ScanArgs {
     int collect_lo, collect_hi;   // collect pass: this launch runs when collect_lo <= *unc_count <= collect_hi
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
-// pipelined form for 256-query blocks (scan8.hip: 8-slot LDS ring, register double-buffering); selected with
-// SQE_SCAN=p8 (SQE_P8_SLOTS=4|2 picks its 4- or 2-barrier K step); the ping-pong form below is the default.
-int launch_scan_bf16_p8(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
-// ping-pong form for 256-query blocks (scan_pp.hip): the two waves of a SIMD alternate between a
-// compute phase and a memory phase.  Environment SQE_SCAN = pp | p8 | v0 picks the 256-query kernel.
+// ping-pong form for 256-query blocks (scan_pp.hip, the default): the two waves of a SIMD alternate between
+// a compute phase and a memory phase.  (Knobs build only: SQE_SCAN=v0 picks the two-stage form of scan.hip.)
 int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // second pass for uncertified queries: same scan, fixed thresholds args.collect_thr, every row at or
 // above its query's threshold goes to args.collect_keys; exits at once when *args.unc_count == 0

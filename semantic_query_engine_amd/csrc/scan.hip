@@ -17,7 +17,7 @@
 // 256-query tile, 3 for the HBM-bound 64-query tile, DB stages 3 deep and query stages 2 deep for the
 // 128-query tile -- what fits in 160 KiB): the kernel of batches <= 128 and of the
 // collect pass, and the A/B baseline for 256-query blocks, whose default is the ping-pong schedule of
-// scan_pp.hip (scan8.hip holds a third schedule).  Both operand tiles go global -> LDS in full 128-B
+// scan_pp.hip.  Both operand tiles go global -> LDS in full 128-B
 // lines; the XOR chunk swizzle c' = c ^ ((row >> 1) & 7) is applied on the per-lane SOURCE
 // address and on the ds_read_b128 address (the LDS image itself stays lane-linear), which
 // makes every fragment read bank-conflict free.
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     f.q_live = min(BN, batch - q0);
     f.trig = p.trig;
     f.per_wave = PER_WAVE;
-    f.dbg_no_slow = (p.dbg & 16) != 0;
-    f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
+    f.dbg_no_slow = (SQE_DBG_BITS(p) & 16) != 0;
+    f.dbg_counters = (SQE_DBG_BITS(p) & 32) ? p.dbg_counters : nullptr;
     constexpr bool collect = COLLECT;                    // second pass for uncertified queries
     f.collect_keys = collect ? p.collect_keys + (size_t)q0 * EXACT_CAP : nullptr;
     f.collect_cnt = collect ? p.collect_cnt + q0 : nullptr;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
 
-        if (ks == KS - 1 && !(p.dbg & 4)) {                 // SQE_DBG bit 4: timing experiment, no filter
+        if (ks == KS - 1 && !(SQE_DBG_BITS(p) & 4)) {                 // SQE_DBG bit 4: timing experiment, no filter
             const int64_t row0 = (int64_t)tile_of(entry) * BM;
             if (entry == 0 && !collect) {
                 filter_boot<FM, FN>(acc, f, row0, wm * (FM * 16), wn * (FN * 16), lane);
@@ -334,8 +334,8 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     k.trig = std::min(CAND_CAP - SCAN_BM, std::max(2 * plan.kp, 128));
     k.ngroups = plan.ngroups; k.gshift = plan.gshift; k.gcomplete = plan.n_chunks / GMAX_COLS;
     {
-        static const int krot = [] { const char* e = getenv("SQE_KROT"); return e ? atoi(e) : 0; }();
-        static const int dbg = [] { const char* e = getenv("SQE_DBG"); return e ? atoi(e) : 0; }();
+        static const int krot = [] { const char* e = knob_env("SQE_KROT"); return e ? atoi(e) : 0; }();
+        static const int dbg = [] { const char* e = knob_env("SQE_DBG"); return e ? atoi(e) : 0; }();
         k.krot = krot;
         k.dbg = dbg;
     }
@@ -369,7 +369,7 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
 
 // SQE_SCAN128=2: the older two-stage ring of the 128-query tile (A/B comparisons)
 static bool bn128_two_stage() {
-    static const bool v = [] { const char* e = getenv("SQE_SCAN128"); return e && e[0] == '2'; }();
+    static const bool v = [] { const char* e = knob_env("SQE_SCAN128"); return e && e[0] == '2'; }();
     return v;
 }
 
@@ -382,23 +382,14 @@ int launch_scan_collect(const ScanPlan& plan, const ScanArgs& a, hipStream_t str
     return launch_cfg<8, 1, 2, 4, 3>(plan, a, stream, true);
 }
 
-constexpr int SCAN_DEFAULT_KERNEL = 2;    // the ping-pong schedule (scan_pp.hip): 1-5 % faster than the two-stage form at every size measured
-
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (a.K % SCAN_BK != 0) return fail(SQE_ERR_INVALID, "scan: dim must be a multiple of 64");
     if (plan.kp < 1 || plan.kp > MAX_KP) return fail(SQE_ERR_INVALID, "scan: kp out of range");
     if (plan.bn == 256) {
-        // 0 = two-stage form below, 1 = scan8.hip, 2 = scan_pp.hip
-        static const int which = [] {
-            const char* e = getenv("SQE_SCAN");
-            if (e && e[0] == 'p' && e[1] == '8') return 1;
-            if (e && e[0] == 'v') return 0;
-            if (e && e[0] == 'p' && e[1] == 'p') return 2;
-            return SCAN_DEFAULT_KERNEL;
-        }();
-        if (which == 1) return launch_scan_bf16_p8(plan, a, stream);
-        if (which == 2) return launch_scan_bf16_pp(plan, a, stream);
-        return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream);
+        // the ping-pong schedule (scan_pp.hip); SQE_SCAN=v0 in a knobs build picks the two-stage form below
+        static const bool two_stage = [] { const char* e = knob_env("SQE_SCAN"); return e && e[0] == 'v'; }();
+        if (two_stage) return launch_cfg<2, 4, 8, 4, 2>(plan, a, stream);
+        return launch_scan_bf16_pp(plan, a, stream);
     }
     if (plan.bn == 128) return bn128_two_stage() ? launch_cfg<4, 2, 4, 4, 2>(plan, a, stream)
                                                  : launch_cfg<4, 2, 4, 4, 3, 2>(plan, a, stream);

@@ -92,6 +92,14 @@ struct FilterLds {
     } while (0)
 #endif
 
+// Timing-experiment bits of ScanKernelArgs::dbg: a compile-time zero unless built with -DSQE_DEBUG_KNOBS,
+// so the shipped kernels carry none of the no-MFMA / no-DMA / no-filter paths.
+#ifdef SQE_DEBUG_KNOBS
+#define SQE_DBG_BITS(p) ((p).dbg)
+#else
+#define SQE_DBG_BITS(p) 0
+#endif
+
 // s_waitcnt vmcnt(0) the compiler can see (expcnt / lgkmcnt fields left at their maxima)
 __device__ __forceinline__ void wait_vm0_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 

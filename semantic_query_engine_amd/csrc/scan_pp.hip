@@ -1,6 +1,6 @@
 // scan_pp.hip -- S2, ping-pong form of the bf16 scan for query blocks of 256 (gfx950).
 //
-// Same contract as scan.hip / scan8.hip (256-row DB tile x 256 queries per persistent workgroup,
+// Same contract as scan.hip (256-row DB tile x 256 queries per persistent workgroup,
 // fused top-k filter, candidate lists).  What differs is how the two waves that share a SIMD
 // are scheduled against each other:
 //
@@ -29,8 +29,7 @@
 //
 //   Filter.  G0 runs one phase ahead of G1, so after its last compute phase of a tile it first loads the
 //     operands of the next tile's first half-step; then both groups filter the finished tile in ONE common
-//     phase (the filter is paid once per tile, not once per group -- SQE_PP_SYNCF=0 restores the older
-//     form, in which each group filtered at the head of its own next MEM phase).  The first compute phase
+//     phase (the filter is paid once per tile, not once per group).  The first compute phase
 //     of a tile takes a zero C operand, so accumulators are never cleared by VALU moves.  Cross-wave
 //     steps (publishing boot maxima, list compaction) run at the start of the phase after the filter.
 //
@@ -90,7 +89,6 @@ struct PP {
     Cursor dm;                             // half-step the next MEM phase fetches (rd + 3)
     int refresh_pending, refresh_ctr, refresh_j;
     int lean_until;                        // MEM phases of half-steps < lean_until take the lean form
-    int b_h, b_stage;                      // SPLIT: query pieces the next compute phase issues (b_h < 0: none)
     bool no_mma, no_dma, no_filter;
 
     __device__ __forceinline__ void advance(Cursor& c) const {
@@ -127,22 +125,14 @@ struct PP {
 // moves.  The kernel's loops are nested (tile entries outside, half-steps inside, the first and
 // the last half-step peeled) so that the two variants never meet at a control-flow merge: with
 // `if (first) ... else ...` inside one flat loop hipcc keeps two accumulator sets and spills.
-template <bool FIRST, bool SPLIT>
-__device__ __forceinline__ void cmp_phase(const PP& P, f32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
+template <bool FIRST>
+__device__ __forceinline__ void cmp_phase(f32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
 #pragma unroll
-    for (int fm = 0; fm < 8; ++fm) {
-        // SPLIT: the computing wave issues the two query pieces of half-step j + 3 between its MFMAs
-        // (the matrix pipe is the only thing it waits for), the loading wave only the DB pieces
-        if (SPLIT && (fm == 2 || fm == 5)) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (P.b_h >= 0) P.issue_b(P.b_h, P.b_stage, fm == 2 ? 0 : 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int fm = 0; fm < 8; ++fm)
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
             acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 a[fm], b[fn], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn], 0, 0, 0);
-    }
 }
 
 // Phase 2j+2 of a tile boundary (j % HS == 0, j > 0): both groups' filters of the finished entry
@@ -165,26 +155,9 @@ __device__ __forceinline__ void entry_sync(const PP& P, const Filter& f, int fin
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// MEMORY phase of half-step j (P.rd): filter work that is due, DMA of half-step j + 3, operand reads.
-// FILTER: this is the first half-step of an entry > 0, the accumulators hold the finished tile.
-template <bool FILTER, bool SPLIT>
-__device__ __forceinline__ void mem_phase(PP& P, const Filter& f, f32x4 (&acc)[8][4], AOps& a, BOps& b, int j) {
+// MEMORY phase of half-step j (P.rd): bound work that is due, DMA of half-step j + 3, operand reads.
+__device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps& b, int j) {
     const bool more = j + 3 < P.J && !P.no_dma;
-
-    // ---- filter of the entry the previous compute phase finished
-    if (FILTER && !P.no_filter) {
-        const int fe = P.rd.e - 1;
-        const int fl = fresh_lane();
-        if (fe == 0) {
-            filter_boot<8, 4>(acc, f, P.row0_of(fe), P.wm * 128, P.wn * 64, fl);
-        } else {
-            // Appended keys are NOT drained: stores that sit between DMA pieces only make the counted
-            // waits below retire more than they must (vmcnt(N) leaves the N youngest operations of any
-            // kind in flight), never less.
-            filter_tile<8, 4>(acc, f, P.row0_of(fe), P.wm * 128, P.wn * 64, fl);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
     // ---- global bound: fold a slice fetched >= 3 half-steps ago (every wave's pieces have been
     // retired by its counted waits and a barrier), then maybe fetch the next one
@@ -192,7 +165,7 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, f32x4 (&acc)[8
         if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
         P.refresh_pending = -1;
     }
-    // Schedule as in scan8.hip: entry 1 fetches all slices back to back from a quarter of the tile on
+    // Schedule: entry 1 fetches all slices back to back from a quarter of the tile on
     // (when every chunk has published its boot maxima), then every slice once per tile while the
     // bound still moves fast, one slice per tile later.  At least 4 half-steps between fetches.
     if (P.gshift >= 0 && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && j >= P.refresh_j + 4) {
@@ -207,13 +180,7 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, f32x4 (&acc)[8
     }
 
     // ---- DMA of half-step j + 3 into the stage of half-step j - 1
-    if (SPLIT) {
-        if (more) P.issue_a(P.dm, (j + 3) & 3);
-        P.b_h = more ? P.dm.h : -1;
-        P.b_stage = (j + 3) & 3;
-    } else {
-        if (more) P.issue(P.dm, (j + 3) & 3);
-    }
+    if (more) P.issue(P.dm, (j + 3) & 3);
 
     // ---- operands of half-step j
     {
@@ -228,7 +195,6 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, f32x4 (&acc)[8
     // Anything else this wave issued in between (bound fetch, appended keys) only makes the wait
     // retire part of j + 2 as well.
     if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else if (SPLIT) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 
     // ---- first half-step that needs this (general) form again; until then mem_lean runs
@@ -244,27 +210,18 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, f32x4 (&acc)[8
 }
 
 // MEMORY phase without filter or bound work, j + 3 < J: the steady-state form.
-template <bool SPLIT>
 __device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j) {
-    if (SPLIT) {
-        P.issue_a(P.dm, (j + 3) & 3);
-        P.b_h = P.dm.h;
-        P.b_stage = (j + 3) & 3;
-    } else {
-        P.issue(P.dm, (j + 3) & 3);
-    }
+    P.issue(P.dm, (j + 3) & 3);
     const char* st = P.smem + (j & 3) * STAGE_BYTES;
 #pragma unroll
     for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + P.rdA + fm * 2048);
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + P.rdB + fn * 2048);
-    if (SPLIT) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     P.advance(P.rd);
     P.advance(P.dm);
 }
 
-template <bool SPLIT, bool SYNCF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -296,8 +253,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
     P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift;
     P.refresh_every = P.HS >= NSLICEP ? P.HS / NSLICEP : 1;
-    P.no_mma = (p.dbg & 1) != 0; P.no_dma = (p.dbg & 2) != 0; P.no_filter = (p.dbg & 4) != 0;
-    if (p.dbg & 8) P.gshift = -1;
+    P.no_mma = (SQE_DBG_BITS(p) & 1) != 0; P.no_dma = (SQE_DBG_BITS(p) & 2) != 0; P.no_filter = (SQE_DBG_BITS(p) & 4) != 0;
+    if (SQE_DBG_BITS(p) & 8) P.gshift = -1;
 
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
@@ -312,8 +269,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     f.q_live = min(BNP, p.B - q0);
     f.trig = p.trig;
     f.per_wave = 32;
-    f.dbg_no_slow = (p.dbg & 16) != 0;
-    f.dbg_counters = (p.dbg & 32) ? p.dbg_counters : nullptr;
+    f.dbg_no_slow = (SQE_DBG_BITS(p) & 16) != 0;
+    f.dbg_counters = (SQE_DBG_BITS(p) & 32) ? p.dbg_counters : nullptr;
     f.collect_keys = nullptr; f.collect_cnt = nullptr;
     for (int i = tid; i < BNP; i += SCAN_THREADS) {
         const bool live = (q0 + i) < p.B;
@@ -349,7 +306,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     P.refresh_pending = -1;
     P.refresh_ctr = 0;
     P.refresh_j = -100;
-    P.b_h = -1; P.b_stage = 0;
     P.lean_until = 0;
 
     f32x4 acc[8][4];
@@ -365,7 +321,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     }
     __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
 
-    if constexpr (SYNCF) {
+    {
         // Both groups filter a finished tile in the SAME phase (no MFMAs in it): G0, one phase ahead, first
         // loads the operands of the next tile's first half-step and then waits for G1's last compute phase.
         // The filter is then paid once per tile instead of once per group.
@@ -383,26 +339,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 __builtin_amdgcn_sched_barrier(0);
             };
             if (group == 0) {
-                mem_phase<false, SPLIT>(P, f, acc, a, b, 0);
+                mem_phase(P, f, a, b, 0);
                 PP_BARRIER();
                 for (int e = 0; e < n_entries; ++e) {
                     if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
-                    if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
+                    if (!P.no_mma) cmp_phase<true>(acc, a, b);
                     PP_BARRIER();
-                    mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                    mem_phase(P, f, a, b, j + 1);
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
-                        if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                        if (!P.no_mma) cmp_phase<false>(acc, a, b);
                         PP_BARRIER();
-                        if (j + 1 < P.lean_until) mem_lean<SPLIT>(P, a, b, j + 1);
-                        else mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                        if (j + 1 < P.lean_until) mem_lean(P, a, b, j + 1);
+                        else mem_phase(P, f, a, b, j + 1);
                         PP_BARRIER();
                         ++j;
                     }
-                    if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                    if (!P.no_mma) cmp_phase<false>(acc, a, b);
                     PP_BARRIER();
-                    if (e + 1 < n_entries) mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
+                    if (e + 1 < n_entries) mem_phase(P, f, a, b, j + 1);
                     PP_BARRIER();
                     ++j;
                     if (e + 1 < n_entries) {
@@ -414,16 +370,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 PP_BARRIER();
                 for (int e = 0; e < n_entries; ++e) {
                     if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
-                    mem_phase<false, SPLIT>(P, f, acc, a, b, j);
+                    mem_phase(P, f, a, b, j);
                     PP_BARRIER();
-                    if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
+                    if (!P.no_mma) cmp_phase<true>(acc, a, b);
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS; ++h) {
-                        if (j < P.lean_until) mem_lean<SPLIT>(P, a, b, j);
-                        else mem_phase<false, SPLIT>(P, f, acc, a, b, j);
+                        if (j < P.lean_until) mem_lean(P, a, b, j);
+                        else mem_phase(P, f, a, b, j);
                         PP_BARRIER();
-                        if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
+                        if (!P.no_mma) cmp_phase<false>(acc, a, b);
                         PP_BARRIER();
                         ++j;
                     }
@@ -431,57 +387,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                         filter_phase(e);
                         PP_BARRIER();
                     }
-                }
-            }
-        }
-    } else
-    if (P.J > 0) {
-        const int HS = P.HS;
-        int j = 0;                         // half-step of the compute phase
-        if (group == 0) {
-            mem_phase<false, SPLIT>(P, f, acc, a, b, 0);
-            PP_BARRIER();
-            for (int e = 0; e < n_entries; ++e) {
-                // h = 0
-                if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
-                PP_BARRIER();
-                if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
-                mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
-                PP_BARRIER();
-                ++j;
-                for (int h = 1; h < HS - 1; ++h) {
-                    if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
-                    PP_BARRIER();
-                    if (j + 1 < P.lean_until) mem_lean<SPLIT>(P, a, b, j + 1);
-                    else mem_phase<false, SPLIT>(P, f, acc, a, b, j + 1);
-                    PP_BARRIER();
-                    ++j;
-                }
-                // h = HS - 1: the next MEM phase opens entry e + 1 and filters entry e
-                if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
-                PP_BARRIER();
-                if (e + 1 < n_entries) mem_phase<true, SPLIT>(P, f, acc, a, b, j + 1);
-                PP_BARRIER();
-                ++j;
-            }
-        } else {
-            PP_BARRIER();
-            for (int e = 0; e < n_entries; ++e) {
-                // h = 0
-                if (e > 0) mem_phase<true, SPLIT>(P, f, acc, a, b, j);
-                else mem_phase<false, SPLIT>(P, f, acc, a, b, j);
-                PP_BARRIER();
-                if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
-                if (!P.no_mma) cmp_phase<true, SPLIT>(P, acc, a, b);
-                PP_BARRIER();
-                ++j;
-                for (int h = 1; h < HS; ++h) {
-                    if (j < P.lean_until) mem_lean<SPLIT>(P, a, b, j);
-                    else mem_phase<false, SPLIT>(P, f, acc, a, b, j);
-                    PP_BARRIER();
-                    if (!P.no_mma) cmp_phase<false, SPLIT>(P, acc, a, b);
-                    PP_BARRIER();
-                    ++j;
                 }
             }
         }
@@ -504,10 +409,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
 int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& a, hipStream_t stream) {
     if (plan.bn != BNP) return fail(SQE_ERR_INVALID, "scan pp: query block must be 256");
     ScanKernelArgs k = make_kernel_args(plan, a);
-    static const bool split = [] { const char* e = getenv("SQE_PP_SPLIT"); return e && e[0] == '1'; }();   // measured slower
-    static const bool syncf = [] { const char* e = getenv("SQE_PP_SYNCF"); return !(e && e[0] == '0'); }();
-    auto kern = syncf ? (split ? scan_bf16_pp_kernel<true, true> : scan_bf16_pp_kernel<false, true>)
-                      : (split ? scan_bf16_pp_kernel<true, false> : scan_bf16_pp_kernel<false, false>);
+    auto kern = scan_bf16_pp_kernel;
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(plan.n_chunks * plan.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
     SQE_HIP(hipGetLastError());

@@ -81,8 +81,8 @@ class Context:
 
     # -- cache scan, one-shot (main.py:73-87)
     def cosine_best(self, mat: np.ndarray, q: np.ndarray) -> Tuple[float, int]:
-        mat = _f32(mat).reshape(-1, q.shape[-1]) if mat.size else np.zeros((0, q.shape[-1]), np.float32)
         q = _f32(q).reshape(-1)
+        mat = _f32(mat).reshape(-1, q.shape[0]) if mat.size else np.zeros((0, q.shape[0]), np.float32)
         sim = C.c_float()
         idx = C.c_int32()
         N.check(self.lib.sqe_cosine_best(self.handle, mat.ctypes.data, mat.shape[0], q.shape[0],
@@ -171,8 +171,10 @@ class VectorIndex:
         N.check(self.lib.sqe_index_add_device(self.handle, ptr, n))
 
     def update(self, rows: np.ndarray, x: np.ndarray) -> None:
-        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
         x = _f32(x)
+        if x.shape != (rows.shape[0], self.dim):
+            raise ValueError(f"expected [{rows.shape[0]}, {self.dim}] array for {rows.shape[0]} rows, got {x.shape}")
         if rows.size:
             N.check(self.lib.sqe_index_update(self.handle, rows.ctypes.data, x.ctypes.data, rows.shape[0]))
 
@@ -248,11 +250,15 @@ class CacheMatrix:
 
     def set_slot(self, slot: int, vec: np.ndarray) -> None:
         vec = _f32(vec).reshape(-1)
+        if vec.shape[0] != self.dim:            # the C side reads dim floats: never hand it a shorter buffer
+            raise ValueError(f"cache embedding has {vec.shape[0]} values, the cache matrix holds {self.dim}-d rows")
         N.check(self.lib.sqe_cache_set_slot(self.handle, slot, vec.ctypes.data))
 
     def best(self, order, q: np.ndarray) -> Tuple[float, int]:
         order = np.ascontiguousarray(order, dtype=np.int32)
         q = _f32(q).reshape(-1)
+        if q.shape[0] != self.dim:
+            raise ValueError(f"query embedding has {q.shape[0]} values, the cache matrix holds {self.dim}-d rows")
         sim = C.c_float()
         pos = C.c_int32()
         N.check(self.lib.sqe_cache_best(self.handle, order.ctypes.data, order.shape[0], q.ctypes.data,

@@ -121,6 +121,53 @@ class GpuSearchClient:
         return True
 
 
+def _commit_documents(idx: "_GpuNamedIndex", embeddings: np.ndarray, docs: List[Dict[str, str]], id_of) -> int:
+    """The "index" op of the bulk call (main.py:318-338): insert, or overwrite an existing ``_id``.
+
+    Order matters: (1) validate and convert the vectors, (2) plan against the docstore WITHOUT touching it,
+    (3) run the device add / update, (4) only then commit ``sources`` / ``row_of_id``.  A failing device call
+    (wrong dimension, allocation failure) therefore leaves host docstore and vector rows in step: every later
+    add still lands at vector row == sources row."""
+    vecs = np.ascontiguousarray(embeddings, dtype=np.float32)
+    if vecs.ndim != 2 or vecs.shape[1] != idx.vectors.dim:
+        raise ValueError(f"embeddings must be [n, {idx.vectors.dim}], got {vecs.shape}")
+    n = min(len(docs), vecs.shape[0])                 # zip() semantics of main.py:318
+    with idx.lock:
+        base = len(idx.sources)
+        new_src: List[Dict[str, str]] = []
+        new_ids: Dict[str, int] = {}                  # _id -> position in this call's insert list
+        new_from: List[int] = []                      # embedding row of each insert (the LAST writer of its _id)
+        upd: Dict[int, tuple] = {}                    # stored row -> (source, embedding row); last writer wins
+        for i in range(n):
+            os_id = id_of(i, docs[i])
+            src = {"doc_id": docs[i]["doc_id"], "text": docs[i]["text"]}
+            row = idx.row_of_id.get(os_id)
+            if row is not None:
+                upd[row] = (src, i)
+            elif os_id in new_ids:                    # same _id twice in one call: the later document replaces the earlier
+                new_src[new_ids[os_id]], new_from[new_ids[os_id]] = src, i
+            else:
+                new_ids[os_id] = len(new_src)
+                new_src.append(src)
+                new_from.append(i)
+        # normalisation x / (||x|| + 1e-9) (main.py:315-316) happens on the GPU
+        if new_from:
+            contiguous = new_from == list(range(new_from[0], new_from[0] + len(new_from)))
+            idx.vectors.add(vecs[new_from[0]:new_from[0] + len(new_from)] if contiguous else vecs[new_from])
+        try:
+            if upd:
+                rows = sorted(upd)
+                idx.vectors.update(np.array(rows, np.int64), vecs[[upd[r][1] for r in rows]])
+        finally:
+            # the appended vector rows exist whatever the update did: their documents must exist too
+            for os_id, pos in new_ids.items():
+                idx.row_of_id[os_id] = base + pos
+            idx.sources.extend(new_src)
+        for row, (src, _i) in upd.items():
+            idx.sources[row] = src
+    return n
+
+
 class OpenSearchIndexer:
     """Drop-in for the reference class of the same name (main.py:291-373)."""
 
@@ -143,30 +190,7 @@ class OpenSearchIndexer:
             return
         try:
             idx = self.client.index(self.index_name)
-            embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
-            n = min(len(docs), embeddings.shape[0])          # zip() semantics of main.py:318
-            with idx.lock:
-                new_rows: List[int] = []
-                upd_rows: List[int] = []
-                upd_src: List[int] = []
-                for i in range(n):
-                    doc_id = docs[i]["doc_id"]
-                    os_id = f"{doc_id}_{i}"                   # main.py:325
-                    src = {"doc_id": doc_id, "text": docs[i]["text"]}
-                    row = idx.row_of_id.get(os_id)
-                    if row is None:                           # "index" op: insert ...
-                        idx.row_of_id[os_id] = len(idx.sources)
-                        idx.sources.append(src)
-                        new_rows.append(i)
-                    else:                                     # ... or overwrite the same _id
-                        idx.sources[row] = src
-                        upd_rows.append(row)
-                        upd_src.append(i)
-                # normalisation x / (||x|| + 1e-9) (main.py:315-316) happens on the GPU
-                if new_rows:
-                    idx.vectors.add(embeddings[new_rows] if len(new_rows) != n else embeddings[:n])
-                if upd_rows:
-                    idx.vectors.update(np.array(upd_rows, np.int64), embeddings[upd_src])
+            n = _commit_documents(idx, embeddings, docs, lambda i, d: f"{d['doc_id']}_{i}")   # _id rule of main.py:325
             print(f"[OpenSearchIndexer] Inserted {n} docs, errors=[]")
         except Exception as e:
             print(f"[OpenSearchIndexer] Bulk indexing error: {e}")

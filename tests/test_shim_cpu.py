@@ -191,6 +191,82 @@ def test_ollama_embeddings_and_microbatching(app_client):
     assert sum(len(b) for b in emb2.calls) == 40 and len(emb2.calls) < 40 and max(len(b) for b in emb2.calls) <= 64
 
 
+def test_concurrent_searches_share_one_batched_scan():
+    """32 concurrent `_search` requests (each B = 1 on the wire, as main.py:499 sends them)
+    reach the index as ONE batched call, and every request still gets exactly its own oracle answer."""
+    class CountingVectors(OracleVectors):
+        def __init__(self, dim):
+            super().__init__(dim)
+            self.search_batches = []
+
+        def search(self, q, k, nprobe=0):
+            self.search_batches.append(np.asarray(q).shape[0])
+            return super().search(q, k, nprobe)
+
+    rng = np.random.default_rng(3)
+    n, nq = 400, 32
+    x = rng.standard_normal((n, DIM)).astype(np.float32)
+    oc = OracleClient(DIM)
+    named = oc.index("idx")
+    named.vectors = CountingVectors(DIM)
+    named.vectors.add(x)
+    named.sources = [{"doc_id": f"PMC{i // 4}.txt", "text": f"chunk {i}"} for i in range(n)]
+    named.row_of_id = {f"PMC{i // 4}.txt_{i}": i for i in range(n)}
+    qs = (x[rng.integers(0, n, nq)] + 0.1 * rng.standard_normal((nq, DIM))).astype(np.float32)
+    ks = [3 if i % 2 else 10 for i in range(nq)]                       # mixed k in one batch
+
+    async def many():
+        app = shim.create_app(oc, None, DIM)
+        import httpx
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://shim") as ac:
+            rs = await asyncio.gather(*[ac.post("/idx/_search", json={"size": ks[i], "query": {"knn": {"embedding": {
+                "vector": [float(v) for v in qs[i]], "k": ks[i]}}}}) for i in range(nq)])
+        return rs, app.state.search_batcher
+    rs, sb = asyncio.run(many())
+    assert all(r.status_code == 200 for r in rs)
+    assert named.vectors.search_batches == [nq] and sb.batches == 1     # one device call for the 32 requests
+    xn = R.normalize_rows(x)
+    for i, r in enumerate(rs):
+        hits = r.json()["hits"]["hits"]
+        cos, want = R.exact_topk(xn, R.normalize_rows(qs[i:i + 1]), ks[i])
+        assert [h["_id"] for h in hits] == [f"PMC{j // 4}.txt_{j}" for j in want[0]]
+        assert all(abs(h["_score"] - 1.0 / (2.0 - float(c))) < 1e-6 for h, c in zip(hits, cos[0]))
+        assert hits[0]["_source"]["text"] == f"chunk {want[0][0]}"
+
+
+def test_failed_device_add_keeps_docstore_and_vectors_in_step():
+    """A bulk request whose device add fails must not leave documents behind: later adds still land at
+    vector row == docstore row, and hits map to the right documents."""
+    class FailingOnce(OracleVectors):
+        fail_next = True
+
+        def add(self, x):
+            if self.fail_next:
+                self.fail_next = False
+                raise RuntimeError("hipMalloc: out of memory")
+            super().add(x)
+
+    oc = OracleClient(DIM)
+    named = oc.index("idx")
+    named.vectors = FailingOnce(DIM)
+    c = TestClient(shim.create_app(oc, None, DIM))
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((6, DIM)).astype(np.float32)
+    docs = [{"doc_id": f"D{i}", "text": f"t{i}"} for i in range(6)]
+    ids = [f"D{i}_{i}" for i in range(6)]
+    j = c.post("/_bulk", content=_bulk_body("idx", ids[:3], docs[:3], x[:3])).json()
+    assert j["errors"] is True and [it["index"]["status"] for it in j["items"]] == [500] * 3
+    assert named.sources == [] and named.row_of_id == {} and len(named.vectors) == 0
+    # a malformed vector (a string inside the list) is a per-document 400, the rest of the request goes through
+    body = _bulk_body("idx", ids[3:], docs[3:], x[3:]).decode().split("\n")
+    bad = json.loads(body[1]); bad["embedding"][0] = "oops"; body[1] = json.dumps(bad)
+    j = c.post("/_bulk", content="\n".join(body).encode()).json()
+    assert [it["index"]["status"] for it in j["items"]] == [400, 201, 201]
+    assert len(named.sources) == len(named.vectors) == 2
+    r = c.post("/idx/_search", json={"size": 1, "query": {"knn": {"embedding": {"vector": [float(v) for v in x[5]], "k": 1}}}})
+    assert r.json()["hits"]["hits"][0]["_id"] == ids[5] and r.json()["hits"]["hits"][0]["_source"]["text"] == "t5"
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

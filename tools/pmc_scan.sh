@@ -13,6 +13,7 @@ for pass in "${mem_passes[@]}" \
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   env "$@" rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}/${name} -- python3 bench.py $args > gpurun_out/pmc_${tag}_${name}.json 2> gpurun_out/pmc_${tag}_${name}.err || echo "pass $name failed"
 done
+sha=$(python3 -c "import bench; print(bench.scan_source_hash())")
 python3 - <<PY
 import csv, glob, collections, json
 tot = {}
@@ -33,7 +34,7 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     # (MI355X_MICROARCH.md, HBM section): double FETCH_SIZE, take WRITE_SIZE as is
     fetch = tot["FETCH_SIZE"] * 1024 * 2
     write = tot["WRITE_SIZE"] * 1024
-    json.dump({"rows": int("${PMC_ROWS:-10000000}"), "batch": int("${PMC_BATCH:-1024}"), "tag": "${tag}",
+    json.dump({"rows": int("${PMC_ROWS:-10000000}"), "batch": int("${PMC_BATCH:-1024}"), "tag": "${tag}", "scan_src_sha": "${sha}",
                "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                "hbm_bytes_per_launch": fetch + write,
                "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, separate --pmc passes, "
