@@ -15,8 +15,14 @@
  *     data in HBM (bench.py, the encoder -> search hand-off, torch.distributed shards)
  *     pays no PCIe copy
  *   - every entry point is thread-safe: the reference calls add_embeddings from a
- *     thread-pool thread while search runs on the event-loop thread (main.py:454-455, 499)
- *   - one context drives ONE device; multi-GPU = one process per GPU (torch.distributed)
+ *     thread-pool thread while search runs on the event-loop thread (main.py:454-455, 499).
+ *     There is no context-wide lock: every index, cache and encoder has its own mutex and its
+ *     own stream (host entry points run there and synchronise it before returning), so an add
+ *     on one index never blocks a search on another, the cache scan or the encoder
+ *   - multi-GPU, two forms: ONE host process driving several devices (sqe_create with
+ *     n_dev > 1: what the reference's single uvicorn process needs, main.py:738-739), or one
+ *     process per GPU over torch.distributed with single-device contexts (bench.py, sharded.py)
+ *   - the library reads no environment variable
  */
 #ifndef SQE_H
 #define SQE_H
@@ -57,8 +63,22 @@ enum { SQE_SCAN_BF16_RESCORE = 0, SQE_SCAN_FP32 = 1 };
 int sqe_version(void);
 const char* sqe_last_error(void);
 
-/* device_ids[0] is the HIP device this context drives (n_dev must be 1). */
+/* n_dev == 1: the context drives HIP device device_ids[0].
+ * n_dev > 1: single process, many devices (the reference is one uvicorn process, main.py:738-739).  The
+ * context leads one member context per device; flat indexes created on it are sharded row-wise (global row g
+ * on shard g % n_dev), a search sends the query batch to every device, runs the per-shard top-k there and
+ * exchanges the packed [B,k] results in ONE step -- RCCL all-gather over xGMI (ncclCommInitAll, one
+ * communicator per device) or, where RCCL is unavailable, peer copies to device_ids[0] -- before the merge
+ * on device_ids[0].  Device pointers of "_device" entry points are memory of device_ids[0].  Caches and
+ * encoders live on device_ids[0] (replicas only); IVF indexes are single-device. */
 int sqe_create(const int* device_ids, int n_dev, sqe_ctx** out);
+/* General form: `exchange` picks the exchange step, and device ids may repeat (several logical shards on
+ * one device -- how a one-GPU box rehearses the sharded path; those use the copy exchange).  A group of ONE
+ * shard with SQE_EXCHANGE_RCCL runs the in-library RCCL leg on a single device. */
+enum { SQE_EXCHANGE_AUTO = 0, SQE_EXCHANGE_RCCL = 1, SQE_EXCHANGE_COPY = 2 };
+int sqe_create_sharded(const int* device_ids, int n_shards, int exchange, sqe_ctx** out);
+/* Shards of the context (1 for a single-device context), the exchange in use and the device of each shard. */
+int sqe_group_info(sqe_ctx* ctx, int* n_shards, int* exchange, int* device_ids, int cap);
 void sqe_destroy(sqe_ctx* ctx);
 int sqe_synchronize(sqe_ctx* ctx);
 /* hipStream_t the "_device" entry points enqueue on (for event timing by the caller). */
@@ -194,13 +214,13 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
 /* When profiling is on, every stage is bracketed by hipEvents on the context stream;
  * sqe_stats reads the accumulated totals (it synchronises the stream). */
 typedef struct sqe_stats_t {
-    double scan_ms;        /* bf16/fp32 scan kernel (the dominant kernel of search) */
+    double scan_ms;        /* bf16 scan kernels: the main launches plus the collect-pass scans of uncertified queries */
     double prep_ms;        /* query normalise + cast */
     double select_ms;      /* candidate merge + fp32 rescore + final top-k */
     double add_ms;         /* normalise + cast of added rows */
     double encode_ms;      /* encoder forward */
     double cache_ms;       /* cache scan */
-    int64_t scan_calls;
+    int64_t scan_calls;    /* main scan launches (the collect pass is not counted) */
     int64_t search_calls;
     int64_t scan_rows;     /* rows scanned by the last search */
     int64_t scan_flops;    /* 2 * rows * dim * B of the last search */

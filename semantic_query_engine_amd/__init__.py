@@ -7,8 +7,8 @@ binding (``_native``), a thin object layer (``engine``) and the host-side mirror
 reference interface (``retrieval``).  There is no CPU fallback: importing ``_native``
 fails loudly when the library has not been built.
 """
-from .engine import (INDEX_FLAT, INDEX_IVF_FLAT, SCAN_BF16_RESCORE, SCAN_FP32, CacheMatrix, Context,
-                     VectorIndex)
+from .engine import (EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL, INDEX_FLAT, INDEX_IVF_FLAT, SCAN_BF16_RESCORE,
+                     SCAN_FP32, CacheMatrix, Context, VectorIndex)
 
 __all__ = ["Context", "VectorIndex", "CacheMatrix", "INDEX_FLAT", "INDEX_IVF_FLAT",
-           "SCAN_BF16_RESCORE", "SCAN_FP32"]
+           "SCAN_BF16_RESCORE", "SCAN_FP32", "EXCHANGE_AUTO", "EXCHANGE_RCCL", "EXCHANGE_COPY"]

@@ -35,6 +35,8 @@ SIGNATURES = {
     "sqe_version": (C.c_int, []),
     "sqe_last_error": (C.c_char_p, []),
     "sqe_create": (C.c_int, [c_i32_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "sqe_create_sharded": (C.c_int, [c_i32_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sqe_group_info": (C.c_int, [C.c_void_p, c_i32_p, c_i32_p, c_i32_p, C.c_int]),
     "sqe_destroy": (None, [C.c_void_p]),
     "sqe_synchronize": (C.c_int, [C.c_void_p]),
     "sqe_stream": (C.c_void_p, [C.c_void_p]),

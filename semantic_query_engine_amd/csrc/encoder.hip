@@ -29,7 +29,7 @@
 
 #include <stdlib.h>
 
-#include "kernels.h"
+#include "internal.h"
 
 namespace sqe {
 
@@ -987,6 +987,7 @@ struct sqe_layer {
 
 struct sqe_encoder {
     sqe_ctx* ctx = nullptr;
+    OpOrder ord;                     // own mutex + stream (internal.h): the encoder never blocks an index or the cache
     sqe_bert_cfg cfg;
     DevMem word, pos, type, emb_g, emb_b;
     std::vector<std::unique_ptr<sqe_layer>> layers;
@@ -1014,17 +1015,7 @@ struct sqe_encoder {
     }
 };
 
-// sqe_ctx internals needed here (defined in api.hip)
-extern "C" void* sqe_stream(sqe_ctx* ctx);
-namespace sqe { int ctx_cu_count(sqe_ctx* ctx); int ctx_device(sqe_ctx* ctx); void ctx_lock(sqe_ctx*); void ctx_unlock(sqe_ctx*); }
-
 namespace {
-
-struct CtxGuard {
-    sqe_ctx* c;
-    explicit CtxGuard(sqe_ctx* ctx) : c(ctx) { ctx_lock(c); (void)hipSetDevice(ctx_device(c)); }
-    ~CtxGuard() { ctx_unlock(c); }
-};
 
 int upload(DevMem& dst, const float* src, size_t n, bool as_bf16, size_t offset_elems, size_t total_elems, hipStream_t st) {
     SQE_TRY(dst.alloc(total_elems * (as_bf16 ? 2 : 4)));
@@ -1054,6 +1045,8 @@ int sqe_encoder_create(sqe_ctx* ctx, const sqe_bert_cfg* cfg, sqe_encoder** out)
     if (!e) return fail(SQE_ERR_OOM, "sqe_encoder_create: host allocation failed");
     e->ctx = ctx;
     e->cfg = *cfg;
+    SQE_HIP(hipSetDevice(ctx->device));
+    SQE_TRY(e->ord.init());
     for (int l = 0; l < cfg->layers; ++l) e->layers.emplace_back(new sqe_layer);
     {
         const char* g = knob_env("SQE_ENC_GRAPH");          // SQE_ENC_GRAPH=0: always launch kernel by kernel
@@ -1065,17 +1058,19 @@ int sqe_encoder_create(sqe_ctx* ctx, const sqe_bert_cfg* cfg, sqe_encoder** out)
 
 void sqe_encoder_destroy(sqe_encoder* enc) {
     if (!enc) return;
+    (void)hipSetDevice(enc->ctx->device);
     {
-        CtxGuard g(enc->ctx);
-        (void)hipStreamSynchronize((hipStream_t)sqe_stream(enc->ctx));
+        std::lock_guard<std::mutex> lk(enc->ord.mu);
+        enc->ord.quiesce();
     }
+    enc->ord.destroy();
     delete enc;
 }
 
 int sqe_encoder_load_tensor(sqe_encoder* enc, const char* name, const float* data_host, const int64_t* shape, int ndim) {
     if (!enc || !name || !data_host || !shape || ndim < 1 || ndim > 2) return fail(SQE_ERR_INVALID, "sqe_encoder_load_tensor: bad arguments");
-    CtxGuard g(enc->ctx);
-    hipStream_t st = (hipStream_t)sqe_stream(enc->ctx);
+    OpScope op(enc->ctx, enc->ord, true);
+    hipStream_t st = op.s;
     const sqe_bert_cfg& c = enc->cfg;
     const size_t H = c.hidden, I = c.inter;
     const std::string n(name);
@@ -1124,6 +1119,7 @@ int sqe_encoder_load_tensor(sqe_encoder* enc, const char* name, const float* dat
 
 int sqe_encoder_finalize(sqe_encoder* enc) {
     if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
+    std::lock_guard<std::mutex> lk(enc->ord.mu);
     const size_t want = 5 + (size_t)enc->cfg.layers * 16;
     if (enc->loaded.size() != want)
         return fail(SQE_ERR_STATE, "sqe_encoder_finalize: " + std::to_string(enc->loaded.size()) + " of " + std::to_string(want) + " tensors loaded");
@@ -1134,14 +1130,11 @@ int sqe_encoder_finalize(sqe_encoder* enc) {
 static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev,
                           int t_pad, hipStream_t st);
 
-int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev) {
-    if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
+// forward pass on stream st (caller holds the encoder's lock)
+static int encode_impl(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev, hipStream_t st) {
     if (!enc->finalized) return fail(SQE_ERR_STATE, "sqe_encode: encoder weights not finalized");
-    if (B < 0 || S < 1 || S > enc->cfg.max_pos) return fail(SQE_ERR_INVALID, "sqe_encode: need 1 <= S <= max_pos");
-    if (B == 0) return SQE_OK;
-    if (!ids_dev || !lens_dev || !out_dev) return fail(SQE_ERR_INVALID, "sqe_encode: null buffer");
-    CtxGuard g(enc->ctx);
-    hipStream_t st = (hipStream_t)sqe_stream(enc->ctx);
+    if (S > enc->cfg.max_pos) return fail(SQE_ERR_INVALID, "sqe_encode: need 1 <= S <= max_pos");
+    StageTimer timer(enc->ctx->prof, st, ST_ENCODE);
     const sqe_bert_cfg& c = enc->cfg;
     const int H = c.hidden, I = c.inter;
     const int T = B * S;
@@ -1170,7 +1163,7 @@ int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* l
     sqe_encoder::GraphEntry* ge = nullptr;
     if (enc->use_graphs && t_pad <= GRAPH_MAX_TOKENS) {
         for (auto& e : enc->graphs)
-            if (e.B == B && e.S == S && e.ids == ids_dev && e.lens == lens_dev && e.out == out_dev) ge = &e;
+            if (e.B == B && e.S == S && e.ids == ids_dev && e.lens == lens_dev && e.out == out_dev) ge = &e;   // replays on any stream
         if (!ge) {
             if (enc->graphs.size() >= GRAPH_CACHE) {              // evict the least recently used entry
                 size_t victim = 0;
@@ -1216,7 +1209,7 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
     const sqe_bert_cfg& c = enc->cfg;
     const int H = c.hidden, I = c.inter;
     const int T = B * S;
-    const int cus = ctx_cu_count(enc->ctx);
+    const int cus = enc->ctx->cu_count;
     const int rows4 = (T + 3) / 4;
     const size_t pstride = (size_t)t_pad * H;             // floats between split-K partial sums in `pre`
     hipLaunchKernelGGL(embed_ln_kernel, dim3(rows4), dim3(256), 0, st, ids_dev, enc->word.as<bf16_t>(), enc->pos.as<bf16_t>(),
@@ -1267,19 +1260,28 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
     return SQE_OK;
 }
 
+int sqe_encode_device(sqe_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S, float* out_dev) {
+    if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
+    if (B < 0 || S < 1) return fail(SQE_ERR_INVALID, "sqe_encode: need 1 <= S <= max_pos");
+    if (B == 0) return SQE_OK;
+    if (!ids_dev || !lens_dev || !out_dev) return fail(SQE_ERR_INVALID, "sqe_encode: null buffer");
+    OpScope op(enc->ctx, enc->ord, false);
+    return encode_impl(enc, ids_dev, lens_dev, B, S, out_dev, op.s);
+}
+
 int sqe_encode(sqe_encoder* enc, const int32_t* ids_host, const int32_t* lens_host, int B, int S, float* out_host) {
     if (!enc) return fail(SQE_ERR_INVALID, "null encoder");
     if (B < 0 || S < 1) return fail(SQE_ERR_INVALID, "sqe_encode: bad shape");
     if (B == 0) return SQE_OK;
     if (!ids_host || !lens_host || !out_host) return fail(SQE_ERR_INVALID, "sqe_encode: null buffer");
-    CtxGuard g(enc->ctx);
-    hipStream_t st = (hipStream_t)sqe_stream(enc->ctx);
+    OpScope op(enc->ctx, enc->ord, true);
+    hipStream_t st = op.s;
     SQE_TRY(enc->ids.alloc((size_t)B * S * 4));
     SQE_TRY(enc->lens.alloc((size_t)B * 4));
     SQE_TRY(enc->out.alloc((size_t)B * enc->cfg.hidden * 4));
     SQE_HIP(hipMemcpyAsync(enc->ids.p, ids_host, (size_t)B * S * 4, hipMemcpyHostToDevice, st));
     SQE_HIP(hipMemcpyAsync(enc->lens.p, lens_host, (size_t)B * 4, hipMemcpyHostToDevice, st));
-    SQE_TRY(sqe_encode_device(enc, enc->ids.as<int32_t>(), enc->lens.as<int32_t>(), B, S, enc->out.as<float>()));
+    SQE_TRY(encode_impl(enc, enc->ids.as<int32_t>(), enc->lens.as<int32_t>(), B, S, enc->out.as<float>(), st));
     SQE_HIP(hipMemcpyAsync(out_host, enc->out.p, (size_t)B * enc->cfg.hidden * 4, hipMemcpyDeviceToHost, st));
     SQE_HIP(hipStreamSynchronize(st));
     return SQE_OK;

@@ -17,34 +17,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "kernels.h"
-
-struct sqe_index;
-struct sqe_ctx;
-
-// internal hooks implemented in api.hip
-namespace sqe {
-float* index_master(sqe_index* idx);
-const bf16_t* index_scan(sqe_index* idx);
-int index_pitch(sqe_index* idx);
-int64_t index_rows(sqe_index* idx);
-int index_dim(sqe_index* idx);
-int index_nlist(sqe_index* idx);
-int64_t index_id_base(sqe_index* idx);
-sqe_ctx* index_ctx(sqe_index* idx);
-void index_clear(sqe_index* idx);
-int index_add_restored(sqe_index* idx, const float* x_dev, int64_t n);
-hipStream_t ctx_stream(sqe_ctx* ctx);
-int ctx_cu_count(sqe_ctx* ctx);
-}  // namespace sqe
-
-extern "C" {
-int sqe_index_create(sqe_ctx* ctx, int dim, int kind, int nlist, sqe_index** out);
-void sqe_index_destroy(sqe_index* idx);
-int sqe_index_add_device(sqe_index* idx, const float* x_dev, int64_t n);
-int sqe_index_search_device(sqe_index* idx, const float* q_dev, int B, int k, int nprobe, float* cos_out_dev,
-                            int64_t* id_out_dev);
-}
+#include "internal.h"
 
 namespace sqe {
 
@@ -115,6 +88,13 @@ __global__ void ivf_store_assign_kernel(const int64_t* __restrict__ ids, int64_t
     const int a = (int)ids[i];
     assign[i] = a;
     if (counts && a >= 0) atomicAdd(counts + a, 1);
+}
+
+// assign[rows[i]] = lists[i] (rows overwritten by sqe_index_update)
+__global__ void ivf_scatter_assign_kernel(const int* __restrict__ lists, const int64_t* __restrict__ rows, int64_t n,
+                                          int* __restrict__ assign) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) assign[rows[i]] = lists[i];
 }
 
 __global__ void ivf_count_kernel(const int* __restrict__ assign, int64_t n, int* __restrict__ counts) {
@@ -673,15 +653,14 @@ struct IvfState {
 // allows it the whole [b, nlist] score matrix is one small GEMM (dense bf16 copies of both sides, fp32 out,
 // the encoder's ring GEMM) followed by a per-row radix select; otherwise the flat index over the centroids.
 static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev, int64_t b, int kk, int64_t* ids_out,
-                           float* cos_out) {
-    sqe_ctx* ctx = index_ctx(base);
-    hipStream_t s = ctx_stream(ctx);
-    const int nlist = index_nlist(base), dim = index_dim(base);
+                           float* cos_out, hipStream_t s) {
+    sqe_ctx* ctx = base->ctx;
+    const int nlist = base->nlist, dim = base->dim;
     const bool dense = nlist % 128 == 0 && (size_t)nlist * 4 <= 64 * 1024 && kk + 8 <= MAX_KP;
-    if (!dense) return sqe_index_search_device(st->coarse, rows_dev, (int)b, kk, 0, cos_out, ids_out);
+    if (!dense) return index_search_impl(st->coarse, rows_dev, (int)b, kk, 0, cos_out, ids_out, s);
     if (st->cent_dirty) {
         SQE_TRY(st->cent_bf16.ensure((size_t)nlist * dim * 2));
-        SQE_TRY(launch_normalize_rows(index_master(st->coarse), nlist, dim, nullptr, st->cent_bf16.as<bf16_t>(), dim, nullptr, nullptr, s));
+        SQE_TRY(launch_normalize_rows(st->coarse->master, nlist, dim, dim, nullptr, st->cent_bf16.as<bf16_t>(), dim, nullptr, nullptr, s));
         st->cent_dirty = false;
     }
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_probe_select_kernel), 64 * 1024));
@@ -693,28 +672,26 @@ static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev,
         const int m = (int)std::min(step, b - off);
         const int t_pad = (m + 127) / 128 * 128;
         if (t_pad > m) SQE_HIP(hipMemsetAsync(st->qd.as<char>() + (size_t)m * dim * 2, 0, (size_t)(t_pad - m) * dim * 2, s));
-        SQE_TRY(launch_normalize_rows(rows_dev + (size_t)off * dim, m, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
+        SQE_TRY(launch_normalize_rows(rows_dev + (size_t)off * dim, m, dim, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
         SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, m, t_pad,
-                                   ctx_cu_count(ctx), s));
+                                   ctx->cu_count, s));
         hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(m), dim3(256), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, kk,
-                           rows_dev + (size_t)off * dim, index_master(st->coarse), dim, ids_out + off * kk, cos_out + off * kk);
+                           rows_dev + (size_t)off * dim, st->coarse->master, dim, ids_out + off * kk, cos_out + off * kk);
         SQE_HIP(hipGetLastError());
     }
     return SQE_OK;
 }
 
 static int ivf_assign_rows(sqe_index* base, IvfState* st, const float* rows_dev, int64_t n, int* assign_out,
-                           int64_t* ids64_out /* optional [n] */) {
+                           int64_t* ids64_out /* optional [n] */, hipStream_t s) {
     // cosine top-1 of `rows_dev` against the centroids, in batches
-    sqe_ctx* ctx = index_ctx(base);
-    hipStream_t s = ctx_stream(ctx);
-    const int dim = index_dim(base);
+    const int dim = base->dim;
     const int64_t batch = 65536;
     SQE_TRY(st->tmp_ids.ensure((size_t)std::min(batch, n) * 8));
     SQE_TRY(st->tmp_cos.ensure((size_t)std::min(batch, n) * 4));
     for (int64_t off = 0; off < n; off += batch) {
         const int b = (int)std::min(batch, n - off);
-        SQE_TRY(ivf_coarse_topk(base, st, rows_dev + (size_t)off * dim, b, 1, st->tmp_ids.as<int64_t>(), st->tmp_cos.as<float>()));
+        SQE_TRY(ivf_coarse_topk(base, st, rows_dev + (size_t)off * dim, b, 1, st->tmp_ids.as<int64_t>(), st->tmp_cos.as<float>(), s));
         if (assign_out)
             hipLaunchKernelGGL(ivf_store_assign_kernel, dim3((b + 255) / 256), dim3(256), 0, s, st->tmp_ids.as<int64_t>(),
                                (int64_t)b, assign_out + off, (int*)nullptr);
@@ -728,7 +705,7 @@ static int ivf_assign_rows(sqe_index* base, IvfState* st, const float* rows_dev,
 int ivf_create(sqe_index* base, IvfState** out) {
     IvfState* st = new (std::nothrow) IvfState;   // (struct defined above)
     if (!st) return fail(SQE_ERR_OOM, "ivf: host allocation failed");
-    int rc = sqe_index_create(index_ctx(base), index_dim(base), SQE_INDEX_FLAT, 0, &st->coarse);
+    int rc = index_create_impl(base->ctx, base->dim, SQE_INDEX_FLAT, 0, true, &st->coarse);
     if (rc != SQE_OK) { delete st; return rc; }
     *out = st;
     return SQE_OK;
@@ -740,30 +717,51 @@ void ivf_destroy(IvfState* st) {
     delete st;
 }
 
-int ivf_rows_added(sqe_index* base, IvfState* st) {
+int ivf_rows_added(sqe_index* base, IvfState* st, hipStream_t s) {
     // assign rows [n_assigned, rows) once the centroids exist
     if (!st->trained) return SQE_OK;
-    const int64_t n = index_rows(base);
+    const int64_t n = base->n.load();
     if (n <= st->n_assigned) return SQE_OK;
-    Buf grown;
-    SQE_TRY(grown.ensure((size_t)n * 4));
-    hipStream_t s = ctx_stream(index_ctx(base));
-    if (st->n_assigned > 0)
-        SQE_HIP(hipMemcpyAsync(grown.p, st->assign.p, (size_t)st->n_assigned * 4, hipMemcpyDeviceToDevice, s));
-    SQE_HIP(hipStreamSynchronize(s));
-    std::swap(grown.p, st->assign.p);
-    std::swap(grown.bytes, st->assign.bytes);
-    SQE_TRY(ivf_assign_rows(base, st, index_master(base) + (size_t)st->n_assigned * index_dim(base), n - st->n_assigned,
-                            st->assign.as<int>() + st->n_assigned, nullptr));
+    if ((size_t)n * 4 > st->assign.bytes) {
+        // grows geometrically: an index fed 64 rows at a time must not copy the whole array on every add
+        Buf grown;
+        SQE_TRY(grown.ensure((size_t)std::max<int64_t>(n, (int64_t)(st->assign.bytes / 4) * 3 / 2) * 4));
+        if (st->n_assigned > 0)
+            SQE_HIP(hipMemcpyAsync(grown.p, st->assign.p, (size_t)st->n_assigned * 4, hipMemcpyDeviceToDevice, s));
+        SQE_HIP(hipStreamSynchronize(s));
+        std::swap(grown.p, st->assign.p);
+        std::swap(grown.bytes, st->assign.bytes);
+    }
+    SQE_TRY(ivf_assign_rows(base, st, base->master + (size_t)st->n_assigned * base->dim, n - st->n_assigned,
+                            st->assign.as<int>() + st->n_assigned, nullptr, s));
     st->n_assigned = n;
     st->lists_dirty = true;
     return SQE_OK;
 }
 
-static int ivf_build_lists(sqe_index* base, IvfState* st) {
-    const int nlist = index_nlist(base);
+// sqe_index_update overwrote `n` stored rows (ids on the device): only those are re-assigned
+int ivf_rows_updated(sqe_index* base, IvfState* st, const int64_t* rows_dev, int64_t n, hipStream_t s) {
+    if (!st->trained || n <= 0) return SQE_OK;
+    SQE_TRY(ivf_rows_added(base, st, s));                 // rows appended since the last search get their list first
+    const int dim = base->dim;
+    Buf rows, lists;
+    SQE_TRY(rows.ensure((size_t)n * dim * 4));
+    SQE_TRY(lists.ensure((size_t)n * 4));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, base->master, rows_dev, (int)n, dim,
+                       rows.as<float>());
+    SQE_HIP(hipGetLastError());
+    SQE_TRY(ivf_assign_rows(base, st, rows.as<float>(), n, lists.as<int>(), nullptr, s));
+    hipLaunchKernelGGL(ivf_scatter_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lists.as<int>(), rows_dev, n,
+                       st->assign.as<int>());
+    SQE_HIP(hipGetLastError());
+    SQE_HIP(hipStreamSynchronize(s));                     // the temporaries die here
+    st->lists_dirty = true;
+    return SQE_OK;
+}
+
+static int ivf_build_lists(sqe_index* base, IvfState* st, hipStream_t s) {
+    const int nlist = base->nlist;
     const int64_t n = st->n_assigned;
-    hipStream_t s = ctx_stream(index_ctx(base));
     SQE_TRY(st->counts.ensure((size_t)nlist * 4));
     SQE_TRY(st->cursor.ensure((size_t)nlist * 4));
     SQE_TRY(st->offsets.ensure((size_t)(nlist + 1) * 8));
@@ -789,16 +787,14 @@ static int ivf_build_lists(sqe_index* base, IvfState* st) {
     return SQE_OK;
 }
 
-int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int iters, uint64_t seed) {
-    const int nlist = index_nlist(base), dim = index_dim(base);
+int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int iters, uint64_t seed, hipStream_t s) {
+    const int nlist = base->nlist, dim = base->dim;
     if (n < nlist) return fail(SQE_ERR_INVALID, "sqe_index_train: need at least nlist training rows");
     if (iters < 1) iters = 1;
-    sqe_ctx* ctx = index_ctx(base);
-    hipStream_t s = ctx_stream(ctx);
     // normalised copy of the sample
     Buf xs, pick, assign64;
     SQE_TRY(xs.ensure((size_t)n * dim * 4));
-    SQE_TRY(launch_normalize_rows(x_dev, n, dim, xs.as<float>(), nullptr, dim, nullptr, nullptr, s));
+    SQE_TRY(launch_normalize_rows(x_dev, n, dim, dim, xs.as<float>(), nullptr, dim, nullptr, nullptr, s));
     // initial centroids: nlist distinct rows of the sample (seeded partial Fisher-Yates)
     std::vector<int64_t> perm(n);
     for (int64_t i = 0; i < n; ++i) perm[i] = i;
@@ -815,10 +811,10 @@ int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int 
     SQE_TRY(st->sums.ensure((size_t)nlist * dim * 4));
     SQE_TRY(st->counts.ensure((size_t)nlist * 4));
     for (int it = 0; it < iters; ++it) {
-        index_clear(st->coarse);
-        SQE_TRY(sqe_index_add_device(st->coarse, st->centroids.as<float>(), nlist));
+        st->coarse->n.store(0);
+        SQE_TRY(index_add_impl(st->coarse, st->centroids.as<float>(), nlist, dim, false, s));
         st->cent_dirty = true;
-        SQE_TRY(ivf_assign_rows(base, st, xs.as<float>(), n, nullptr, assign64.as<int64_t>()));
+        SQE_TRY(ivf_assign_rows(base, st, xs.as<float>(), n, nullptr, assign64.as<int64_t>(), s));
         SQE_HIP(hipMemsetAsync(st->sums.p, 0, (size_t)nlist * dim * 4, s));
         SQE_HIP(hipMemsetAsync(st->counts.p, 0, (size_t)nlist * 4, s));
         hipLaunchKernelGGL(kmeans_accum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, xs.as<float>(), assign64.as<int64_t>(), n,
@@ -827,27 +823,39 @@ int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int 
                            st->counts.as<int>(), nlist, dim);
         SQE_HIP(hipGetLastError());
     }
-    index_clear(st->coarse);
-    SQE_TRY(sqe_index_add_device(st->coarse, st->centroids.as<float>(), nlist));
+    st->coarse->n.store(0);
+    SQE_TRY(index_add_impl(st->coarse, st->centroids.as<float>(), nlist, dim, false, s));
     SQE_HIP(hipStreamSynchronize(s));
     st->trained = true;
     st->cent_dirty = true;
     st->n_assigned = 0;                    // (re)assign everything stored so far
     st->lists_dirty = true;
-    return ivf_rows_added(base, st);
+    return ivf_rows_added(base, st, s);
 }
 
-int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, int nprobe, float* cos_out, int64_t* id_out) {
+int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, int nprobe, float* cos_out, int64_t* id_out,
+               hipStream_t s) {
     if (!st->trained) return fail(SQE_ERR_STATE, "sqe_index_search: IVF index is not trained (sqe_index_train)");
-    const int nlist = index_nlist(base), dim = index_dim(base);
+    const int nlist = base->nlist, dim = base->dim;
     if (nprobe <= 0) nprobe = 32;
     nprobe = std::min(std::min(nprobe, nlist), MAX_KP);
-    sqe_ctx* ctx = index_ctx(base);
-    hipStream_t s = ctx_stream(ctx);
-    SQE_TRY(ivf_rows_added(base, st));
-    if (st->lists_dirty) SQE_TRY(ivf_build_lists(base, st));
+    SQE_TRY(ivf_rows_added(base, st, s));
+    if (st->lists_dirty) SQE_TRY(ivf_build_lists(base, st, s));
     const int max_len = (std::max(st->max_len, 1) + 3) / 4 * 4;        // strips are written 4 floats at a time
-    const int pitch = index_pitch(base);
+    // The score strips are [queries, nprobe, longest list] floats.  One over-long list (duplicate-heavy or
+    // tightly clustered data) must not turn that into terabytes: the batch is cut into sub-batches whose
+    // strips fit a fixed budget, each a complete search of its queries.
+    constexpr size_t STRIP_BUDGET = 6ull << 30;
+    const size_t per_query = (size_t)nprobe * max_len * 4;
+    const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, STRIP_BUDGET / per_query));
+    if (sub < B) {
+        for (int off = 0; off < B; off += sub) {
+            const int m = std::min(sub, B - off);
+            SQE_TRY(ivf_search(base, st, q_dev + (size_t)off * dim, m, k, nprobe, cos_out + (size_t)off * k, id_out + (size_t)off * k, s));
+        }
+        return SQE_OK;
+    }
+    const int pitch = base->pitch;
     const int kp = std::min(MAX_KP, std::max(32, 4 * k));
     SQE_TRY(st->qn.ensure((size_t)B * dim * 4));
     SQE_TRY(st->qb.ensure((size_t)(B + LS_Q) * pitch));
@@ -855,28 +863,28 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     SQE_TRY(st->probes_ids.ensure((size_t)B * nprobe * 8));
     SQE_TRY(st->lcount.ensure((size_t)nlist * 4));
     SQE_TRY(st->lq.ensure((size_t)nlist * B * 4));
-    SQE_TRY(st->pair_scores.ensure((size_t)B * nprobe * max_len * 4));
-    SQE_TRY(launch_normalize_rows(q_dev, B, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
+    SQE_TRY(st->pair_scores.ensure((size_t)B * per_query));
+    SQE_TRY(launch_normalize_rows(q_dev, B, dim, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
     // S5: coarse quantise
-    SQE_TRY(ivf_coarse_topk(base, st, q_dev, B, nprobe, st->probes_ids.as<int64_t>(), st->probes_cos.as<float>()));
+    SQE_TRY(ivf_coarse_topk(base, st, q_dev, B, nprobe, st->probes_ids.as<int64_t>(), st->probes_cos.as<float>(), s));
     SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)nlist * 4, s));
     hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
                        st->lcount.as<int>(), st->lq.as<int>(), B);
     // S6: list scan
-    static const bool fp32_lists = [] { const char* e = knob_env("SQE_IVF_FP32"); return e && e[0] == '1'; }();
+    static const bool fp32_lists = [] { const char* e = knob_env("SQE_IVF_FP32"); return e && e[0] == '1'; }();   // knobs build only
     if (fp32_lists) {
-        hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, index_master(base), st->qn.as<float>(), st->order.as<int>(),
+        hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, base->master, st->qn.as<float>(), st->order.as<int>(),
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>());
     } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel), LS_LDS));
-        hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, index_scan(base), pitch, st->qb.as<bf16_t>(),
+        hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, base->scan, pitch, st->qb.as<bf16_t>(),
                            pitch, st->order.as<int>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe,
                            dim, max_len, st->pair_scores.as<float>());
     }
     hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
-                       st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, index_id_base(base),
-                       index_master(base), st->qn.as<float>(), dim, cos_out, id_out);
+                       st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, base->id_base,
+                       base->master, st->qn.as<float>(), dim, cos_out, id_out);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
@@ -887,11 +895,10 @@ sqe_index* ivf_coarse(IvfState* st) { return st->coarse; }
 bool ivf_trained(IvfState* st) { return st->trained; }
 
 // sqe_index_load: centroids (normalised, as exported) and the per-row list assignment of a saved index
-int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const int32_t* assign_dev, int64_t n) {
-    const int nlist = index_nlist(base);
-    hipStream_t s = ctx_stream(index_ctx(base));
-    index_clear(st->coarse);
-    SQE_TRY(index_add_restored(st->coarse, centroids_dev, nlist));
+int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const int32_t* assign_dev, int64_t n, hipStream_t s) {
+    const int nlist = base->nlist;
+    st->coarse->n.store(0);
+    SQE_TRY(index_add_impl(st->coarse, centroids_dev, nlist, base->dim, true, s));
     SQE_TRY(st->assign.ensure((size_t)std::max<int64_t>(n, 1) * 4));
     if (n > 0) SQE_HIP(hipMemcpyAsync(st->assign.p, assign_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     SQE_HIP(hipStreamSynchronize(s));
@@ -903,12 +910,11 @@ int ivf_restore(sqe_index* base, IvfState* st, const float* centroids_dev, const
 }
 
 // introspection for tests / tools: centroids and assignments as stored
-int ivf_export(sqe_index* base, IvfState* st, float* centroids_host, int32_t* assign_host) {
+int ivf_export(sqe_index* base, IvfState* st, float* centroids_host, int32_t* assign_host, hipStream_t s) {
     if (!st->trained) return fail(SQE_ERR_STATE, "ivf export: not trained");
-    hipStream_t s = ctx_stream(index_ctx(base));
-    SQE_TRY(ivf_rows_added(base, st));
+    SQE_TRY(ivf_rows_added(base, st, s));
     if (centroids_host)
-        SQE_HIP(hipMemcpyAsync(centroids_host, index_master(st->coarse), (size_t)index_nlist(base) * index_dim(base) * 4,
+        SQE_HIP(hipMemcpyAsync(centroids_host, st->coarse->master, (size_t)base->nlist * base->dim * 4,
                                hipMemcpyDeviceToHost, s));
     if (assign_host && st->n_assigned > 0)
         SQE_HIP(hipMemcpyAsync(assign_host, st->assign.p, (size_t)st->n_assigned * 4, hipMemcpyDeviceToHost, s));

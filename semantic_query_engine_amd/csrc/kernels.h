@@ -12,11 +12,12 @@ namespace sqe {
 // its rows so that consecutive rows do not map to the same memory channel).
 // `resid_rows` (per row) / `resid_max` (atomic max, float bits) receive || x_hat - bf16(x_hat) ||_2;
 // either may be null.
-int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
+// `x_stride` = floats between consecutive INPUT rows (>= dim: a strided view, e.g. every P-th row of a block).
+int launch_normalize_rows(const float* x, int64_t n, int dim, int64_t x_stride, float* out_f32, bf16_t* out_bf16,
                           int bf16_pitch, float* resid_rows, uint32_t* resid_max, hipStream_t stream);
 // Rows that are already normalised (read back from a saved index): out_f32 = x bit for bit, bf16 copy
 // and residual rebuilt (sqe_index_load).
-int launch_restore_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
+int launch_restore_rows(const float* x, int64_t n, int dim, int64_t x_stride, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
                         uint32_t* resid_max, hipStream_t stream);
 // Same, rows scattered to out row ids `rows[i]` (sqe_index_update).
 int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
@@ -118,9 +119,12 @@ int launch_compact_uncertified(const float* collect_thr, int B, const bf16_t* qb
 // K % 64 == 0, X holds t_pad % 128 == 0 rows.  The encoder's small-batch GEMM (encoder.hip); IVF coarse scores.
 int launch_scores_gemm(const bf16_t* W, const bf16_t* X, float* out, int N, int K, int T, int t_pad, int cu_count, hipStream_t stream);
 
-// merge of [P,B,k] partial results (multi-GPU all-gather output)
+// merge of [P,B,k] partial results (multi-GPU all-gather output).  A valid id of part p is mapped to
+// id * id_mul + p * id_part_add + id_add before it is compared and written: (1, 0, 0) for parts that already
+// hold global ids (torch.distributed row shards), (P, 1, base) for the round-robin shards of a device group.
 int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,
-                      int P, int B, int k, float* cos_out, int64_t* id_out, hipStream_t stream);
+                      int P, int B, int k, float* cos_out, int64_t* id_out, int64_t id_mul, int64_t id_part_add, int64_t id_add,
+                      hipStream_t stream);
 
 // ------------------------------------------------------------------ cache scan (S8)
 // sims[i] = cosine(mat[slot(i)], q) with the zero-norm rule; slot(i) = order ? order[i] : i.

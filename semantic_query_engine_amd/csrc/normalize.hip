@@ -37,7 +37,7 @@ __device__ __forceinline__ float emit_vec(float4 v, float den, float4* dst, uint
 template <int NV, bool SCATTER>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x,
                                                              const int64_t* __restrict__ rows,
-                                                             int64_t n, int dim,
+                                                             int64_t n, int dim, int64_t x_stride,
                                                              float* __restrict__ out_f32,
                                                              bf16_t* __restrict__ out_bf16, int bf16_pitch,
                                                              float* __restrict__ resid_rows,
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     const int nvec = dim >> 2;
     float wave_resid = 0.f;
     for (int64_t row = wave0; row < n; row += nwaves) {
-        const float4* src = reinterpret_cast<const float4*>(x + row * dim);
+        const float4* src = reinterpret_cast<const float4*>(x + row * x_stride);
         float4 v[NV > 0 ? NV : 1];
         float ss = 0.f;
         if constexpr (NV > 0) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 
 namespace {
 template <bool SCATTER>
-int launch_rows(const float* x, const int64_t* rows, int64_t n, int dim, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
+int launch_rows(const float* x, const int64_t* rows, int64_t n, int dim, int64_t x_stride, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
                 float* resid_rows, uint32_t* resid_max, int restore, hipStream_t stream) {
     // 8 blocks of 4 waves per CU (32 waves per CU: full occupancy at <= 64 VGPRs), rows dealt round-robin
     int dev = 0, cus = 256;
@@ -112,7 +112,7 @@ int launch_rows(const float* x, const int64_t* rows, int64_t n, int dim, float* 
     const dim3 grid((unsigned)blocks), block(256);
     const int nvec = dim >> 2;
 #define SQE_NORM_LAUNCH(NVV)                                                                                   \
-    hipLaunchKernelGGL((normalize_rows_kernel<NVV, SCATTER>), grid, block, 0, stream, x, rows, n, dim, out_f32, \
+    hipLaunchKernelGGL((normalize_rows_kernel<NVV, SCATTER>), grid, block, 0, stream, x, rows, n, dim, x_stride, out_f32, \
                        out_bf16, bf16_pitch, resid_rows, resid_max, restore)
     if (nvec <= 64) SQE_NORM_LAUNCH(1);
     else if (nvec <= 128) SQE_NORM_LAUNCH(2);
@@ -125,20 +125,22 @@ int launch_rows(const float* x, const int64_t* rows, int64_t n, int dim, float* 
 }
 }  // namespace
 
-int launch_normalize_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16,
+int launch_normalize_rows(const float* x, int64_t n, int dim, int64_t x_stride, float* out_f32, bf16_t* out_bf16,
                           int bf16_pitch, float* resid_rows, uint32_t* resid_max, hipStream_t stream) {
     if (n <= 0) return SQE_OK;
     if (dim % 4 != 0 || bf16_pitch % 4 != 0 || bf16_pitch < dim)
         return fail(SQE_ERR_INVALID, "normalize: dim and pitch must be multiples of 4, pitch >= dim");
-    return launch_rows<false>(x, nullptr, n, dim, out_f32, out_bf16, bf16_pitch, resid_rows, resid_max, 0, stream);
+    if (x_stride < dim || x_stride % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: input row stride must be a multiple of 4, >= dim");
+    return launch_rows<false>(x, nullptr, n, dim, x_stride, out_f32, out_bf16, bf16_pitch, resid_rows, resid_max, 0, stream);
 }
 
-int launch_restore_rows(const float* x, int64_t n, int dim, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
+int launch_restore_rows(const float* x, int64_t n, int dim, int64_t x_stride, float* out_f32, bf16_t* out_bf16, int bf16_pitch,
                         uint32_t* resid_max, hipStream_t stream) {
     if (n <= 0) return SQE_OK;
     if (dim % 4 != 0 || bf16_pitch % 4 != 0 || bf16_pitch < dim)
         return fail(SQE_ERR_INVALID, "restore: dim and pitch must be multiples of 4, pitch >= dim");
-    return launch_rows<false>(x, nullptr, n, dim, out_f32, out_bf16, bf16_pitch, nullptr, resid_max, 1, stream);
+    if (x_stride < dim || x_stride % 4 != 0) return fail(SQE_ERR_INVALID, "restore: input row stride must be a multiple of 4, >= dim");
+    return launch_rows<false>(x, nullptr, n, dim, x_stride, out_f32, out_bf16, bf16_pitch, nullptr, resid_max, 1, stream);
 }
 
 int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n, int dim,
@@ -147,7 +149,7 @@ int launch_normalize_rows_scatter(const float* x, const int64_t* rows, int64_t n
     if (n <= 0) return SQE_OK;
     if (dim % 4 != 0) return fail(SQE_ERR_INVALID, "normalize: dim must be a multiple of 4");
     if (bf16_pitch % 4 != 0 || bf16_pitch < dim) return fail(SQE_ERR_INVALID, "normalize: pitch must be a multiple of 4, >= dim");
-    return launch_rows<true>(x, rows, n, dim, out_f32, out_bf16, bf16_pitch, nullptr, resid_max, 0, stream);
+    return launch_rows<true>(x, rows, n, dim, dim, out_f32, out_bf16, bf16_pitch, nullptr, resid_max, 0, stream);
 }
 
 }  // namespace sqe

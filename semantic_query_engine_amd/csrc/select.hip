@@ -202,7 +202,8 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const char* __restrict__
                                                         int64_t cos_stride, int64_t id_stride,
                                                         int P, int B, int k,
                                                         float* __restrict__ cos_out,
-                                                        int64_t* __restrict__ id_out) {
+                                                        int64_t* __restrict__ id_out,
+                                                        int64_t id_mul, int64_t id_part_add, int64_t id_add) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
     const int total = P * k;
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const char* __restrict__
     };
     auto ident = [&](int e) {
         const int part = e / k, j = e - part * k;
-        return reinterpret_cast<const int64_t*>(id_parts + part * id_stride)[(size_t)q * k + j];
+        const int64_t raw = reinterpret_cast<const int64_t*>(id_parts + part * id_stride)[(size_t)q * k + j];
+        return raw < 0 ? raw : raw * id_mul + part * id_part_add + id_add;      // shard-local -> global row id
     };
     // rank by counting: entry e beats f when cos higher, or equal cos and lower id
     int valid = 0;
@@ -264,14 +266,15 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
 }
 
 int launch_merge_topk(const float* cos_parts, const int64_t* id_parts, int64_t part_stride_bytes,
-                      int P, int B, int k, float* cos_out, int64_t* id_out, hipStream_t stream) {
+                      int P, int B, int k, float* cos_out, int64_t* id_out, int64_t id_mul, int64_t id_part_add, int64_t id_add,
+                      hipStream_t stream) {
     if (B <= 0) return SQE_OK;
     if (P < 1 || k < 1) return fail(SQE_ERR_INVALID, "merge: P and k must be >= 1");
     const int64_t cs = part_stride_bytes ? part_stride_bytes : (int64_t)B * k * 4;
     const int64_t is = part_stride_bytes ? part_stride_bytes : (int64_t)B * k * 8;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(64), 0, stream,
                        reinterpret_cast<const char*>(cos_parts), reinterpret_cast<const char*>(id_parts),
-                       cs, is, P, B, k, cos_out, id_out);
+                       cs, is, P, B, k, cos_out, id_out, id_mul, id_part_add, id_add);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

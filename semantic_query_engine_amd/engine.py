@@ -24,17 +24,38 @@ def _f32(a: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-class Context:
-    """One MI355X device (one process per GPU; ``device`` is the local HIP ordinal)."""
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
 
-    def __init__(self, device: int = 0):
+
+class Context:
+    """One MI355X device (``device``: the local HIP ordinal -- the form used with one process per GPU), or
+    ONE host process driving several (``devices=[0, 1, ...]``: flat indexes created on the context are
+    sharded row-wise over them and searched with one exchange step, RCCL all-gather or peer copies;
+    device pointers handed to the ``*_device`` calls are memory of ``devices[0]``).  Repeating a device id
+    makes logical shards on one device (``exchange`` then has to be AUTO or COPY)."""
+
+    def __init__(self, device: int = 0, devices=None, exchange: int = EXCHANGE_AUTO):
         self.lib = N.load()
-        ids = (C.c_int32 * 1)(device)
         h = C.c_void_p()
-        N.check(self.lib.sqe_create(ids, 1, C.byref(h)))
+        if devices is None:
+            ids = (C.c_int32 * 1)(device)
+            N.check(self.lib.sqe_create(ids, 1, C.byref(h)))
+            self.devices = [device]
+        else:
+            self.devices = [int(d) for d in devices]
+            ids = (C.c_int32 * len(self.devices))(*self.devices)
+            N.check(self.lib.sqe_create_sharded(ids, len(self.devices), exchange, C.byref(h)))
         self.handle = h
-        self.device = device
+        self.device = self.devices[0]
         self._children = weakref.WeakSet()      # indexes / caches that must die first
+
+    def group_info(self) -> dict:
+        """{"shards": P, "exchange": "rccl" | "copy", "devices": [...]} (one shard for a single-device context)."""
+        n, ex = C.c_int32(), C.c_int32()
+        devs = (C.c_int32 * 64)()
+        N.check(self.lib.sqe_group_info(self.handle, C.byref(n), C.byref(ex), devs, 64))
+        return {"shards": n.value, "exchange": {EXCHANGE_RCCL: "rccl", EXCHANGE_COPY: "copy"}.get(ex.value, "auto"),
+                "devices": list(devs[:n.value])}
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -36,14 +36,19 @@ _default_ctx: Optional[Context] = None
 _ctx_lock = threading.Lock()
 
 
-def default_context(device: Optional[int] = None) -> Context:
-    """Process-wide context (one process per GPU: LOCAL_RANK picks the device)."""
+def default_context(device: Optional[int] = None, devices=None) -> Context:
+    """Process-wide context.  ``devices=[0, 1, ...]``: this one process drives all of them (what the
+    reference's single uvicorn process needs); otherwise one device -- ``device``, or LOCAL_RANK in the
+    one-process-per-GPU form."""
     global _default_ctx
     with _ctx_lock:
         if _default_ctx is None:
             import os
-            dev = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-            _default_ctx = Context(dev)
+            if devices is not None:
+                _default_ctx = Context(devices=devices)
+            else:
+                dev = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+                _default_ctx = Context(dev)
         return _default_ctx
 
 
@@ -64,8 +69,10 @@ class GpuSearchClient:
     embedding_gen.py:211 are just more names)."""
 
     def __init__(self, ctx: Optional[Context] = None, dim: int = EMBED_DIM, kind: int = INDEX_FLAT,
-                 nlist: int = 0):
-        self.ctx = ctx or default_context()
+                 nlist: int = 0, devices=None):
+        """``devices=[0, ..., 7]``: every index of this client is sharded over those GPUs of the node, driven
+        from this one process (ignored when a context is passed)."""
+        self.ctx = ctx or default_context(devices=devices)
         self.dim, self.kind, self.nlist = dim, kind, nlist
         self._indexes: Dict[str, _GpuNamedIndex] = {}
         self._lock = threading.Lock()

@@ -43,7 +43,7 @@ def test_concurrent_add_and_search_and_cache():
 
     def cacher():
         try:
-            cache = SemanticLfuCache(ctx, max_items=50)
+            cache = SemanticLfuCache(ctx, max_items=50, dim=dim)
             for it in range(200):
                 v = base[it:it + 1]
                 cache.put(v, f"r{it}")
