@@ -78,6 +78,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16 (lo in bits 0-15), round to nearest even, in ONE instruction (v_cvt_pk_bf16_f32, new
+// on gfx950); NaN -> quiet NaN.  The encoder's epilogues use it; the index keeps f32_to_bf16 above, whose
+// rounding the exactness certificate's residual is measured against.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
 // Order-preserving map float -> uint32 (larger float <=> larger uint); NaNs are
 // never fed to it (they fail the `s >= thr` filter first).
 __device__ __forceinline__ uint32_t f32_orderable(float f) {

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             } else {
                 if (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
                 uint2 w2;
-                w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                w2.x = pack_bf16x2(v0, v1);
+                w2.y = pack_bf16x2(v2, v3);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
             }
         }
@@ -321,14 +321,15 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
                         const uint2 r2 = res[EPI == EPI_RESID ? i : 0][EPI == EPI_RESID ? j : 0];
                         v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
                         v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
-                        store_f4_asm(reinterpret_cast<float*>(p.out) + o, f32x4{v0, v1, v2, v3});
-                    } else {
-                        if (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-                        uint2 w2;
-                        w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                        w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
-                        store_b64_asm(reinterpret_cast<bf16_t*>(p.out) + o, w2);
+                    } else if (EPI == EPI_GELU) {
+                        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
                     }
+                    // (the pre-LayerNorm sums of EPI_RESID leave as bf16 too: half the bytes written here and
+                    // read by the LayerNorm kernel; the small-batch kernels keep fp32 split-K partial sums)
+                    uint2 w2;
+                    w2.x = pack_bf16x2(v0, v1);
+                    w2.y = pack_bf16x2(v2, v3);
+                    store_b64_asm(reinterpret_cast<bf16_t*>(p.out) + o, w2);
                 }
             }
             tile += gridDim.x;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
 }
 
 template <int EPI>
-int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream) {
+int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, int* splits_out = nullptr) {
     constexpr int LDS = 2 * (256 + 256) * ROWB;
     GemmArgs p = a;
     p.n_tiles = a.N / 256;
@@ -356,6 +357,7 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count)), dim3(512), LDS, stream, p);
     SQE_HIP(hipGetLastError());
+    if (EPI == EPI_RESID && splits_out) *splits_out = 0;      // 0 partial sums: one bf16 row
     return SQE_OK;
 }
 
@@ -464,8 +466,8 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
             } else {
                 if (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
                 uint2 w2;
-                w2.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                w2.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                w2.x = pack_bf16x2(v0, v1);
+                w2.y = pack_bf16x2(v2, v3);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
             }
         }
@@ -581,8 +583,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     } else {
         if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         uint2 w2;
-        w2.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-        w2.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        w2.x = pack_bf16x2(v.x, v.y);
+        w2.y = pack_bf16x2(v.z, v.w);
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
     }
 }
@@ -602,7 +604,8 @@ int launch_gemm_skinny(const GemmArgs& a, int cu_count, size_t split_stride, int
 }
 
 // 256x256 tiles when there are enough tokens to fill the chip with them, the 128x128 ring kernel otherwise.
-// *splits_out = number of fp32 partial sums written (EPI_RESID), `split_stride` floats apart.
+// *splits_out = number of fp32 partial sums written (EPI_RESID), `split_stride` floats apart; 0 = the output is
+// ONE bf16 row per token (the persistent kernel).
 template <int EPI>
 int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, size_t split_stride = 0,
                 int* splits_out = nullptr) {
@@ -615,7 +618,7 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
     if (big) {
         static const bool old_form = [] { const char* e = knob_env("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
-        if (!old_form) return launch_gemm_persistent<EPI>(a, t_pad, cu_count, stream);
+        if (!old_form) return launch_gemm_persistent<EPI>(a, t_pad, cu_count, stream, splits_out);
         GemmArgs p = a;
         p.splits = 1; p.split_stride = 0; p.t_tiles = 0;
         return launch_gemm_cfg<8, 4, EPI>(p, t_pad, stream);
@@ -632,14 +635,24 @@ int scores_gemm(const bf16_t* W, const bf16_t* X, float* out, int N, int K, int 
 
 // ------------------------------------------------------------------ LayerNorm family
 // one wave per row; H % 4 == 0; two passes over registers-or-cache (row <= 16 KiB)
-// row element i = sum over the nsplit split-K partial sums (stride floats apart); nsplit = 1: plain row
+// row element i = sum over the nsplit split-K partial sums (stride floats apart); nsplit = 1: plain fp32 row;
+// nsplit = 0: the row is bf16 (`row` then points at bf16 data: ln_row() does the addressing)
 __device__ __forceinline__ float4 ln_load(const float* row, int i, int nsplit, size_t stride) {
+    if (nsplit == 0) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(row) + i);
+        return make_float4(bf16_to_f32((bf16_t)(w.x & 0xffff)), bf16_to_f32((bf16_t)(w.x >> 16)),
+                           bf16_to_f32((bf16_t)(w.y & 0xffff)), bf16_to_f32((bf16_t)(w.y >> 16)));
+    }
     float4 v = *reinterpret_cast<const float4*>(row + i);
     for (int s = 1; s < nsplit; ++s) {
         const float4 w = *reinterpret_cast<const float4*>(row + (size_t)s * stride + i);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
     return v;
+}
+// first element of row `r` of the pre-LayerNorm buffer in either form
+__device__ __forceinline__ const float* ln_row(const float* in, size_t r, int H, int nsplit) {
+    return nsplit == 0 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(in) + r * H) : in + r * H;
 }
 
 __device__ __forceinline__ void ln_stats(const float* row, int H, int lane, float& mean, float& rstd, float eps,
@@ -690,7 +703,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
-    const float* x = in + (size_t)row * H;
+    const float* x = ln_row(in, (size_t)row, H, nsplit);
     float mean, rstd;
     float4 vr[4];
     if (ln_row_regs(x, H, lane, eps, nsplit, stride, vr, mean, rstd)) {
@@ -702,8 +715,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 const float4 gg = *reinterpret_cast<const float4*>(g + i);
                 const float4 bb = *reinterpret_cast<const float4*>(b + i);
                 uint2 w;
-                w.x = (uint32_t)f32_to_bf16((v.x - mean) * rstd * gg.x + bb.x) | ((uint32_t)f32_to_bf16((v.y - mean) * rstd * gg.y + bb.y) << 16);
-                w.y = (uint32_t)f32_to_bf16((v.z - mean) * rstd * gg.z + bb.z) | ((uint32_t)f32_to_bf16((v.w - mean) * rstd * gg.w + bb.w) << 16);
+                w.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
+                w.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
                 *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = w;
             }
         return;
@@ -714,8 +727,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const float4 gg = *reinterpret_cast<const float4*>(g + i);
         const float4 bb = *reinterpret_cast<const float4*>(b + i);
         uint2 w;
-        w.x = (uint32_t)f32_to_bf16((v.x - mean) * rstd * gg.x + bb.x) | ((uint32_t)f32_to_bf16((v.y - mean) * rstd * gg.y + bb.y) << 16);
-        w.y = (uint32_t)f32_to_bf16((v.z - mean) * rstd * gg.z + bb.z) | ((uint32_t)f32_to_bf16((v.w - mean) * rstd * gg.w + bb.w) << 16);
+        w.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
+        w.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
         *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = w;
     }
 }
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seq >= B) return;
-    const float* x = in + (size_t)seq * S * H;
+    const float* x = ln_row(in, (size_t)seq * S, H, nsplit);
     float mean, rstd;
     float4 vr[4];
     if (ln_row_regs(x, H, lane, eps, nsplit, stride, vr, mean, rstd)) {
@@ -787,8 +800,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
         const float4 gg = *reinterpret_cast<const float4*>(g + i);
         const float4 bb = *reinterpret_cast<const float4*>(b + i);
         uint2 w;
-        w.x = (uint32_t)f32_to_bf16((v.x - mean) * rstd * gg.x + bb.x) | ((uint32_t)f32_to_bf16((v.y - mean) * rstd * gg.y + bb.y) << 16);
-        w.y = (uint32_t)f32_to_bf16((v.z - mean) * rstd * gg.z + bb.z) | ((uint32_t)f32_to_bf16((v.w - mean) * rstd * gg.w + bb.w) << 16);
+        w.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
+        w.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
         *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = w;
     }
 }

@@ -39,7 +39,7 @@ struct ScanPlan {
     int n_chunks;         // DB chunks (persistent workgroups per query block)
     int tiles_per_chunk;  // ceil(n_tiles / n_chunks): the longest chunk (tiles are dealt out evenly)
     int kp;               // candidates kept per (chunk, query)
-    int ngroups;          // rows of the global-bound table per query slice: chunk c publishes to gmax[q][c / 64][c % 64]
+    int ngroups;          // rows of the global-bound table per query slice (1: chunk c folds its maxima into column c % 64)
     int gshift;           // log2 group size of the global bound (64 >> gshift >= kp); -1 = off
 };
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count);

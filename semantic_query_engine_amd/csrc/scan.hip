@@ -332,7 +332,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     // a list is cut back to its best kp when it reaches `trig`; the window trig - kp (>= 64) is what one
     // compaction buys, and a tile can add SCAN_BM entries on top before the next check
     k.trig = std::min(CAND_CAP - SCAN_BM, std::max(2 * plan.kp, 128));
-    k.ngroups = plan.ngroups; k.gshift = plan.gshift; k.gcomplete = plan.n_chunks / GMAX_COLS;
+    k.ngroups = plan.ngroups; k.gshift = plan.gshift;
     {
         static const int krot = [] { const char* e = knob_env("SQE_KROT"); return e ? atoi(e) : 0; }();
         static const int dbg = [] { const char* e = knob_env("SQE_DBG"); return e ? atoi(e) : 0; }();
@@ -353,17 +353,17 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     p.n_tiles = (int)((n_rows + SCAN_BM - 1) / SCAN_BM);
     int chunks = cu_count / p.qblocks;                 // one persistent workgroup per CU
     if (chunks < 1) chunks = 1;
-    // chunk c publishes to row c / 64, column c % 64 of the global-bound table; the rows that are complete
-    // (64 chunks) serve as bound for everybody, so the chunk count need not be a multiple of 64
+    // chunk c folds its maxima into column c % 64 of the global-bound table (one row per query slice), so the
+    // chunk count need not be a multiple of 64
     if (chunks > p.n_tiles) chunks = p.n_tiles > 0 ? p.n_tiles : 1;
     // tiles are dealt out evenly (chunk_tile_range): exactly `chunks` chunks, none empty
     p.n_chunks = chunks;
     p.tiles_per_chunk = p.n_tiles > 0 ? (p.n_tiles + chunks - 1) / chunks : 0;
     p.kp = kp;
-    p.ngroups = (p.n_chunks + GMAX_COLS - 1) / GMAX_COLS;
+    p.ngroups = 1;
     // global bound: 64 >> gshift groups, each contributing one distinct row, must be >= kp
     p.gshift = kp <= 16 ? 2 : kp <= 32 ? 1 : kp <= 64 ? 0 : -1;
-    if (p.n_chunks < GMAX_COLS) p.gshift = -1;          // no complete row: no cross-chunk bound
+    if (p.n_chunks < GMAX_COLS) p.gshift = -1;          // a column without a chunk: no cross-chunk bound
     return p;
 }
 

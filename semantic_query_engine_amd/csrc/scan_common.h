@@ -6,14 +6,18 @@
 //     (LDS), a candidate list (global, CAND_CAP slots) and the best score it has seen.
 //   * A row survives when its key exceeds the threshold.  The threshold is the maximum of
 //       - the LOCAL bound: the kp-th best key of this chunk so far (set by list compaction);
-//       - the GLOBAL bound: every chunk publishes its per-query maximum score to a small
-//         table gmax[query slice of 64][group][64 columns][64 queries]; for the 64 published
-//         maxima m_0..m_63 of a query (64 distinct real rows) min over g-sized groups of
+//       - the GLOBAL bound: every chunk folds its per-query maximum score (atomic max) into
+//         column c % 64 of a small table gmax[query slice of 64][64 columns][64 queries]; a
+//         column holds the maximum over the chunks that share it -- disjoint sets of rows, so
+//         the 64 columns of a query name 64 distinct real rows -- and min over g-sized groups of
 //         max-in-group is a score that at least 64/g >= kp distinct rows reach, hence a lower
 //         bound of the final kp-th best score.  With all chunks streaming in parallel this
 //         bound tracks the whole index, not one chunk, so survivors become rare after the
-//         first few tiles.  (Columns-major inside a slice: a lane owns a query and walks the
-//         64 columns with conflict-free LDS reads, no cross-lane traffic.)
+//         first few tiles; with more than 64 chunks (batches <= 768: up to 256 chunks) every
+//         column is the maximum of up to four chunks, which puts the bound 4 x deeper into the
+//         tail than a table row per 64 chunks did (r01), for the same one-row fetch.
+//         (Columns-major inside a slice: a lane owns a query and walks the 64 columns with
+//         conflict-free LDS reads, no cross-lane traffic.)
 //   * The first tile of a chunk runs in BOOT mode: it only folds per-lane maxima into the
 //     chunk maximum (no appends, so no first-tile append storm); that tile is scanned again,
 //     normally, at the end of the chunk.
@@ -46,16 +50,14 @@ struct ScanKernelArgs {
     int qblocks;
     int kp;
     int trig;            // compaction trigger (kp <= trig <= CAND_CAP - SCAN_BM)
-    int ngroups;         // chunk c publishes to gmax[q][c / 64][c % 64]
-    int gcomplete;       // groups whose 64 columns all exist (n_chunks / 64); chunks of a partial last group read
-                         //   their bound from a complete one (any complete row = 64 distinct rows of the index)
+    int ngroups;         // table rows per query slice (1: chunk c folds its maxima into column c % 64)
     int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
     int krot;            // workgroup w walks K rotated by w * krot steps
     int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter,
                          //   8 = no global-bound refresh, 16 = filter fast path only
     uint64_t* cand;
     int* cand_cnt;
-    uint32_t* gmax;      // [b_pad/64][ngroups][GMAX_COLS][64] orderable scores, 0 = nothing yet
+    uint32_t* gmax;      // [b_pad/64][GMAX_COLS][64] orderable scores, 0 = nothing yet
     unsigned long long* dbg_counters;   // [8] or null: 0 appends, 1 slow-path wave entries, 2 compactions
     // COLLECT mode (second pass for queries whose certificate failed): fixed per-query thresholds,
     // every row at or above them is appended to a per-query global buffer; no lists, no bound exchange
@@ -131,20 +133,20 @@ __device__ __forceinline__ void chunk_tile_range(int n_tiles, int n_chunks, int 
     end = begin + base + (chunk < rem ? 1 : 0);
 }
 
-// Table rows of chunk `chunk`: the one it publishes to (+ its column) and the one it reads its bound from.
+// The table row of a query block and the column chunk `chunk` folds its maxima into (shared with the chunks
+// c + 64, c + 128, ...: all of them hold different rows of the index).
 __device__ __forceinline__ void bound_rows(const ScanKernelArgs& p, int chunk, int q0, const uint32_t*& read_row, uint32_t*& mine) {
-    const int grp = chunk / GMAX_COLS, col = chunk % GMAX_COLS;
-    const int rgrp = (p.gcomplete <= 0 || grp < p.gcomplete) ? grp : grp % p.gcomplete;
     uint32_t* slice0 = p.gmax + (size_t)(q0 / 64) * p.ngroups * (GMAX_COLS * 64);
-    read_row = slice0 + (size_t)rgrp * (GMAX_COLS * 64);
-    mine = slice0 + (size_t)grp * (GMAX_COLS * 64) + col * 64;
+    read_row = slice0;
+    mine = slice0 + (chunk % GMAX_COLS) * 64;
 }
 
 // host: kernel argument block from a plan (scan.hip)
 ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a);
 
-__device__ __forceinline__ void store_sc1_u32(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// fold a chunk maximum into its (shared) table column: device-scope atomic max, no return value
+__device__ __forceinline__ void publish_max_u32(uint32_t* p, uint32_t v) {
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------- compaction
@@ -244,19 +246,22 @@ __device__ __forceinline__ void publish_cmax(const Filter& f, int first_q, int p
     if (lane < per_wave && first_q + lane < f.q_live) {
         const uint32_t m = f.cmax[first_q + lane];
         const int q = first_q + lane;
-        if (m) store_sc1_u32(f.gmax_mine + (size_t)(q >> 6) * f.gstride + (q & 63), m);
+        if (m) publish_max_u32(f.gmax_mine + (size_t)(q >> 6) * f.gstride + (q & 63), m);
     }
 }
 
 // Normal mode.  Returns true when this wave stored candidates (the caller drains its stores
 // before the next barrier so other waves can read the lists).
+// `cols`: wave-uniform mask of the column groups to look at (the ping-pong kernel finds the groups that hold a
+// survivor under its MFMAs -- pp_colmax -- and only those come here); all groups by default.
 template <int FM, int FN, bool COLLECT = false>
 __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Filter& f, int64_t tile_row0,
-                                            int row0, int col0, int lane) {
+                                            int row0, int col0, int lane, unsigned cols = ~0u) {
     bool stored = false;
     const int64_t row_base = tile_row0 + row0 + (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
+        if (!(cols & (1u << j))) continue;
         const int qcol = col0 + j * 16 + (lane & 15);
         const float thr = f.thr_s[qcol];
         float fmx[FM];
@@ -268,6 +273,11 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
         }
         if (__any(mx >= thr) && !f.dbg_no_slow) {    // rare: some lane of this column group has a survivor
             SQE_COUNT(f, 1, lane == 0);
+            // One LDS round trip per appended key (the slot counter): the query's threshold key and the chunk
+            // maximum are read once up here.  Both only rise, so a stale value only admits a key the next
+            // compaction drops again, or publishes a maximum that is already known.
+            const uint64_t tkey = f.thr_key[qcol];
+            const uint32_t cmax0 = f.cmax[qcol];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (__any(fmx[i] >= thr)) {
@@ -278,7 +288,7 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                             const int64_t row = row_base + i * 16 + r;
                             if (row < f.n_rows && qcol < f.q_live) {
                                 const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
-                                if (key > f.thr_key[qcol]) {
+                                if (key > tkey) {
                                     if constexpr (COLLECT) {
                                         const int gslot = atomicAdd(&f.collect_cnt[qcol], 1);
                                         if (gslot < EXACT_CAP) f.collect_keys[(size_t)qcol * EXACT_CAP + gslot] = key;
@@ -289,8 +299,10 @@ __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Fi
                                     f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;
                                     if (slot + 1 >= f.trig) f.flags[qcol / f.per_wave] = 1;
                                     const uint32_t o = (uint32_t)(key >> 32);
-                                    if (o > atomicMax(&f.cmax[qcol], o))
-                                        store_sc1_u32(f.gmax_mine + (size_t)(qcol >> 6) * f.gstride + (qcol & 63), o);
+                                    if (o > cmax0) {
+                                        atomicMax(&f.cmax[qcol], o);      // no return value: fire and forget
+                                        publish_max_u32(f.gmax_mine + (size_t)(qcol >> 6) * f.gstride + (qcol & 63), o);
+                                    }
                                     stored = true;
                                 }
                             }

@@ -27,11 +27,16 @@
 //     before an earlier barrier.  A counted wait at the end of MEM(j) retires this wave's DMA of
 //     half-step j + 1 (issued two of its MEM phases earlier) and leaves j + 2 and j + 3 in flight.
 //
-//   Filter.  G0 runs one phase ahead of G1, so after its last compute phase of a tile it first loads the
-//     operands of the next tile's first half-step; then both groups filter the finished tile in ONE common
-//     phase (the filter is paid once per tile, not once per group).  The first compute phase
-//     of a tile takes a zero C operand, so accumulators are never cleared by VALU moves.  Cross-wave
-//     steps (publishing boot maxima, list compaction) run at the start of the phase after the filter.
+//   Filter.  The fast-path test of a finished tile costs no time of its own: the last half-step of a tile issues
+//     its MFMAs column group by column group (cmp_phase_last); a group's 8 accumulators are final after 8 MFMAs
+//     and its test -- 16 v_max3_i32 and one compare against the query thresholds -- issues under the MFMAs of the
+//     next group, leaving a wave-uniform mask of the groups that hold a survivor and, if there is one, a mark
+//     in LDS.  G0 runs one phase ahead of G1, so after its last compute phase of a tile it first loads the
+//     operands of the next tile's first half-step; then, ONLY IF some wave marked a survivor, both groups run
+//     the slow path (appends to the candidate lists) of their marked column groups in one common phase,
+//     followed by the cross-wave steps (publishing boot maxima, list compaction).  A tile without survivors
+//     goes straight on.  The first compute phase of a tile takes a zero C operand, so accumulators are never
+//     cleared by VALU moves.  (r01 ran fast and slow path of every tile in a common phase without MFMAs.)
 //
 //   This is the default schedule for 256-query blocks (scan.hip: SCAN_DEFAULT_KERNEL); measured against
 //   the two-stage form it is 1-5 % faster at every index size and batch tried (profiles/r01_search).
@@ -135,8 +140,60 @@ __device__ __forceinline__ void cmp_phase(f32x4 (&acc)[8][4], const AOps& a, con
                 a[fm], b[fn], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn], 0, 0, 0);
 }
 
-// Phase 2j+2 of a tile boundary (j % HS == 0, j > 0): both groups' filters of the finished entry
-// are behind a barrier.  Every wave takes the same path (the flags are stable here).
+// Fast-path test in the INTEGER domain: for scores compared against a threshold t >= 0, "some score >= t" is
+// "max over the float bits read as int32 >= bits(t)" -- positive floats order like their bits, every negative
+// float is a negative int, and a finished accumulator is never -0.0 (the sum starts from a +0.0 C operand).
+// v_max3_i32 needs no NaN quieting (fmaxf costs a canonicalising v_max per input under IEEE mode), a NaN
+// score is a large int and merely flags its group for the slow path, which compares in float.  Thresholds
+// below zero (the first tiles of a chunk) flag everything: int32 minimum.
+__device__ __forceinline__ int pp_thr_bits(float t) { return t >= 0.f ? __float_as_int(t) : (int)0x80000000; }
+
+// running max over the four scores of one accumulator fragment: 2 v_max3_i32
+__device__ __forceinline__ int pp_fold(int m, const f32x4& v) {
+    m = max(max(m, __float_as_int(v[0])), __float_as_int(v[1]));
+    return max(max(m, __float_as_int(v[2])), __float_as_int(v[3]));
+}
+
+// Last half-step of a tile (never the first: K >= 64 gives two half-steps): MFMAs column group by column group;
+// the MFMA of fragment (fm, fn) is followed by the two v_max3_i32 that fold fragment (fm, fn - 1) -- final for 8
+// MFMAs by then -- into that group's running maximum, the order requested with sched_group_barrier, so the test
+// of three of the four groups rides under the MFMAs (one MFMA = 16 cycles of the matrix pipe, the two VALU
+// instructions issue beside it).  Returns the wave-uniform mask of the column groups in which some lane
+// holds a score >= its query's threshold (thr: this lane's four thresholds as pp_thr_bits, read from LDS at
+// the head of the phase; thresholds only rise, so an older one only flags more).
+__device__ __forceinline__ unsigned cmp_phase_last(f32x4 (&acc)[8][4], const AOps& a, const BOps& b, const int (&thr)[4]) {
+    int mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        // An empty asm makes group fn - 1's chain of folds start after group fn - 2's has ended: the scheduler
+        // fills the VALU slots of the pipeline below with whatever is ready, and without this order it takes
+        // the folds of the fragment the last MFMA has just written (8 wait states + the MFMA's latency each).
+        if (fn > 1) asm("" : "+v"(mx[fn - 1]) : "v"(mx[fn - 2]));
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) {
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+            if (fn > 0) mx[fn - 1] = pp_fold(mx[fn - 1], acc[fm][fn - 1]);
+        }
+    }
+    asm("" : "+v"(mx[3]) : "v"(mx[2]));
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) mx[3] = pp_fold(mx[3], acc[fm][3]);
+    // the pipeline this region is scheduled to: 8 MFMAs, then 24 x (one MFMA, the two v_max3_i32 of the fragment
+    // eight MFMAs back); the last group's 16 v_max3_i32 and the four compares follow
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+    for (int t = 0; t < 24; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mask |= __any(mx[j] >= thr[j]) ? (1u << j) : 0u;
+    return __builtin_amdgcn_readfirstlane(mask);
+}
+
+// After the barrier that ends the common slow-path phase of a finished entry.  Every wave takes the same path
+// (the flags are stable here).
 __device__ __forceinline__ void entry_sync(const PP& P, const Filter& f, int finished_entry) {
     const int fl = fresh_lane();
     if (finished_entry == 0) {
@@ -322,30 +379,44 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
 
     {
-        // Both groups filter a finished tile in the SAME phase (no MFMAs in it): G0, one phase ahead, first
-        // loads the operands of the next tile's first half-step and then waits for G1's last compute phase.
-        // The filter is then paid once per tile instead of once per group.
-        //     G0: .. CMP(e,last) | MEM(e+1,0) | FILTER(e) | CMP(e+1,0) | MEM(e+1,1) ..
-        //     G1: .. MEM(e,last) | CMP(e,last)| FILTER(e) | MEM(e+1,0) | CMP(e+1,0) ..
+        //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [SLOW(e) sync] | CMP(e+1,0) | MEM(e+1,1) ..
+        //     G1: .. MEM(e,last) | CMP_LAST(e)| [SLOW(e) sync] | MEM(e+1,0) | CMP(e+1,0) ..
         if (P.J > 0) {
             const int HS = P.HS;
             int j = 0;
-            auto filter_phase = [&](int e) {
-                if (!P.no_filter) {
-                    const int fl = fresh_lane();
-                    if (e == 0) filter_boot<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl);
-                    else filter_tile<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl);
-                }
+            unsigned cols = 0;                 // column groups of the finished tile that hold a survivor
+            int thr[4];
+            int* any_cols = f.flags + 8;       // some wave of the workgroup marked a survivor in this tile
+            auto load_thr = [&]() {            // thresholds for the fast-path test, read one phase early
+                const int fl = fresh_lane();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) thr[c] = pp_thr_bits(f.thr_s[P.wn * 64 + c * 16 + (fl & 15)]);
+            };
+            auto last_phase = [&]() {
+                if (!P.no_mma) cols = cmp_phase_last(acc, a, b, thr);
+                if (cols != 0 && fresh_lane() == 0) *any_cols = 1;
+            };
+            // after the barrier that ends G1's last compute phase of entry e: every wave takes the same path
+            auto tile_end = [&](int e) {
+                if (P.no_filter) return;
+                const bool any = e == 0 || __builtin_amdgcn_readfirstlane(*any_cols) != 0;
+                if (!any) return;
+                const int fl = fresh_lane();
+                if (e == 0) filter_boot<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl);
+                else if (cols) filter_tile<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl, cols);
                 __builtin_amdgcn_sched_barrier(0);
+                PP_BARRIER();
+                if (tid == 0) *any_cols = 0;   // read again a whole tile (2 * HS barriers) later
+                entry_sync(P, f, e);
             };
             if (group == 0) {
                 mem_phase(P, f, a, b, 0);
                 PP_BARRIER();
                 for (int e = 0; e < n_entries; ++e) {
-                    if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
                     PP_BARRIER();
                     mem_phase(P, f, a, b, j + 1);
+                    if (HS == 2) load_thr();
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
@@ -353,29 +424,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                         PP_BARRIER();
                         if (j + 1 < P.lean_until) mem_lean(P, a, b, j + 1);
                         else mem_phase(P, f, a, b, j + 1);
+                        if (h == HS - 2) load_thr();
                         PP_BARRIER();
                         ++j;
                     }
-                    if (!P.no_mma) cmp_phase<false>(acc, a, b);
+                    last_phase();
                     PP_BARRIER();
                     if (e + 1 < n_entries) mem_phase(P, f, a, b, j + 1);
                     PP_BARRIER();
                     ++j;
-                    if (e + 1 < n_entries) {
-                        filter_phase(e);
-                        PP_BARRIER();
-                    }
+                    if (e + 1 < n_entries) tile_end(e);
                 }
             } else {
                 PP_BARRIER();
                 for (int e = 0; e < n_entries; ++e) {
-                    if (e > 0 && !P.no_filter) entry_sync(P, f, e - 1);
                     mem_phase(P, f, a, b, j);
                     PP_BARRIER();
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
                     PP_BARRIER();
                     ++j;
-                    for (int h = 1; h < HS; ++h) {
+                    for (int h = 1; h < HS - 1; ++h) {
                         if (j < P.lean_until) mem_lean(P, a, b, j);
                         else mem_phase(P, f, a, b, j);
                         PP_BARRIER();
@@ -383,10 +451,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                         PP_BARRIER();
                         ++j;
                     }
-                    if (e + 1 < n_entries) {
-                        filter_phase(e);
-                        PP_BARRIER();
-                    }
+                    if (j < P.lean_until) mem_lean(P, a, b, j);
+                    else mem_phase(P, f, a, b, j);
+                    load_thr();
+                    PP_BARRIER();
+                    last_phase();
+                    PP_BARRIER();
+                    ++j;
+                    if (e + 1 < n_entries) tile_end(e);
                 }
             }
         }

@@ -18,8 +18,9 @@ KNOBS_LIB = os.path.join(ROOT, "semantic_query_engine_amd", "libsqe_knobs.so")
 
 @pytest.fixture(scope="module")
 def knobs_env():
-    if not os.path.exists(KNOBS_LIB):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "semantic_query_engine_amd", "csrc"), "KNOBS=1", "-j8"])
+    # always through make: a knobs library left over from an older tree must not be the one that is tested
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "semantic_query_engine_amd", "csrc"), "KNOBS=1", "-j8"],
+                          stdout=subprocess.DEVNULL)
     return dict(os.environ, SQE_LIB=KNOBS_LIB)
 
 CHILD = r"""
