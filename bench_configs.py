@@ -55,6 +55,18 @@ def random_bert_weights(cfg=BERT_LARGE, seed: int = 0):
     return out
 
 
+def encoder_flops(tokens: int, s: int) -> float:
+    """per token 24 * 2 * (4 * 1024^2 + 2 * 1024 * 4096) = 604 MFLOP of GEMMs plus
+    24 * 4 * S * 1024 of attention (654 MFLOP per token at S = 512)."""
+    return float(tokens) * (24 * 2 * (4 * 1024 * 1024 + 2 * 1024 * 4096) + 24 * 4 * s * 1024)
+
+
+def mfma_roofline(flops: float, ms: float) -> dict:
+    tf = flops / ms / 1e9
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "traffic": None, "algorithmic_flops": flops}
+
+
 def timed(fn, sync, iters, warmup=2):
     for _ in range(warmup):
         fn()
@@ -100,9 +112,15 @@ def mode_e2e(args, ctx, dev):
         torch.cuda.synchronize()
         enc_ms = timed(lambda: enc.encode_ids_device(ids.data_ptr(), lens.data_ptr(), 64, s, emb.data_ptr()), ctx.synchronize, 10)
         srch_ms = timed(lambda: idx.search_device(emb.data_ptr(), 64, 10, cos.data_ptr(), idk.data_ptr()), ctx.synchronize, 10)
-        flops = 64 * s * (24 * 2 * (4 * 1024 * 1024 + 2 * 1024 * 4096) + 24 * 4 * s * 1024)
+        flops = encoder_flops(64 * s, s)
+        # search at B = 64 is HBM-bound: one read of the bf16 scan copy (N * D * 2 + B * D * 4 + B * k * 12)
+        sbytes = args.rows * D * 2 + 64 * D * 4 + 64 * 10 * 12
         out["cases"].append({"seq_len": s, "encode_ms": round(enc_ms, 3), "search_ms": round(srch_ms, 3),
-                             "encode_tflops": round(flops / enc_ms / 1e9, 1)})
+                             "encode_tflops": round(flops / enc_ms / 1e9, 1),
+                             "roofline_encode": mfma_roofline(flops, enc_ms),
+                             "roofline_search": {"bound": "hbm", "achieved": round(sbytes / srch_ms / 1e6, 1), "peak": 8000.0,
+                                                 "unit": "GB/s", "frac": round(sbytes / srch_ms / 1e6 / 8000.0, 4), "traffic": None,
+                                                 "algorithmic_bytes": sbytes}})
     print(json.dumps(out), flush=True)
 
 
@@ -117,19 +135,45 @@ def mode_encode(args, ctx, dev):
     emb = torch.empty((b, D), device=dev)
     torch.cuda.synchronize()
     ms = timed(lambda: enc.encode_ids_device(ids.data_ptr(), lens.data_ptr(), b, s, emb.data_ptr()), ctx.synchronize, 3, 1)
-    flops = b * s * (24 * 2 * (4 * 1024 * 1024 + 2 * 1024 * 4096) + 24 * 4 * s * 1024)
+    flops = encoder_flops(b * s, s)
     print(json.dumps({"mode": "encode", "batch": b, "seq_len": s, "ms": round(ms, 2), "tokens_per_s": round(b * s / ms * 1e3),
                       "chunks_per_s": round(b / ms * 1e3, 1), "mfma_tflops": round(flops / ms / 1e9, 1),
-                      "frac_of_bf16_peak": round(flops / ms / 1e9 / 2500.0, 4)}), flush=True)
+                      "frac_of_bf16_peak": round(flops / ms / 1e9 / 2500.0, 4), "roofline": mfma_roofline(flops, ms)}), flush=True)
+
+
+def build_clustered(ctx, rows, dev, centres, kind, nlist, keep_host=None):
+    """Clustered index of SURVEY 8(d) (4096 Gaussian centres x sigma 0.3), block by block; `keep_host` (a list)
+    receives the raw blocks as NumPy arrays for the CPU oracle."""
+    from semantic_query_engine_amd import VectorIndex
+    idx = VectorIndex(ctx, D, kind, nlist)
+    idx.reserve(rows)
+    for b in range((rows + BLOCK - 1) // BLOCK):
+        n = min(BLOCK, rows - b * BLOCK)
+        g = torch.Generator(device=dev).manual_seed(1000 + b)
+        x = torch.randn((n, D), generator=g, device=dev)
+        lab = torch.randint(0, centres.shape[0], (n,), generator=g, device=dev)
+        x = centres[lab] + 0.3 * x
+        torch.cuda.synchronize()
+        idx.add_device(x.data_ptr(), n)
+        ctx.synchronize()
+        if keep_host is not None:
+            keep_host.append(x.cpu().numpy())
+        del x
+    return idx
 
 
 def mode_ivf(args, ctx, dev):
-    from semantic_query_engine_amd import INDEX_IVF_FLAT
+    """Config 5.  Two checks of the IVF answer on a 64-query probe, neither of them the HIP flat scan:
+    `parity_vs_oracle_ivf` = share of returned ids equal to oracle.retrieval.ivf_search run on the centroids and
+    list assignment the index exports; `recall_at_10_vs_exact` = recall against an independent exact scan (torch
+    fp32 matmul over the same rows).  The flat index is timed beside it on the same data."""
+    from oracle import retrieval as R      # checker only: never timed here
+    from semantic_query_engine_amd import INDEX_FLAT, INDEX_IVF_FLAT
     g = torch.Generator(device=dev).manual_seed(99)
     centres = torch.randn((4096, D), generator=g, device=dev)
     nlist, nprobe, b, k = 4096, 32, args.batch, 10
-    flat = build_random_index(ctx, args.rows, dev, clustered=centres)
-    ivf = build_random_index(ctx, args.rows, dev, INDEX_IVF_FLAT, nlist, clustered=centres)
+    host_blocks = []
+    ivf = build_clustered(ctx, args.rows, dev, centres, INDEX_IVF_FLAT, nlist, keep_host=host_blocks)
     # train on a 1M-row sample (the first block of the same recipe), 20 Lloyd iterations, seed 0
     gs = torch.Generator(device=dev).manual_seed(1000)
     n_s = min(BLOCK, args.rows)
@@ -144,15 +188,46 @@ def mode_ivf(args, ctx, dev):
     del xs
     gq = torch.Generator(device=dev).manual_seed(5)
     q = centres[torch.randint(0, 4096, (b,), generator=gq, device=dev)] + 0.3 * torch.randn((b, D), generator=gq, device=dev)
-    cf = torch.empty((b, k), device=dev); jf = torch.empty((b, k), dtype=torch.int64, device=dev)
     ci = torch.empty((b, k), device=dev); ji = torch.empty((b, k), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-    flat_ms = timed(lambda: flat.search_device(q.data_ptr(), b, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
     ivf_ms = timed(lambda: ivf.search_device(q.data_ptr(), b, k, ci.data_ptr(), ji.data_ptr(), nprobe=nprobe), ctx.synchronize, 5)
-    hits = sum(len(set(a.tolist()) & set(r.tolist())) for a, r in zip(ji.cpu(), jf.cpu()))
+    # ---- the checks (64-query probe)
+    probe = torch.cat([torch.arange(0, 32), torch.arange(b - 32, b)]).to(dev) if b >= 64 else torch.arange(b, device=dev)
+    got = ji[probe].cpu().numpy()
+    qp = q[probe]
+    qn = qp / (qp.norm(dim=1, keepdim=True) + 1e-9)
+    best_s = torch.full((probe.numel(), 0), -1e30, device=dev)
+    best_i = torch.zeros((probe.numel(), 0), dtype=torch.long, device=dev)
+    lo = 0
+    for blk in host_blocks:                                # independent exact scan, block by block
+        x = torch.from_numpy(blk).to(dev)
+        xn = x / (x.norm(dim=1, keepdim=True) + 1e-9)
+        sc = torch.cat([best_s, qn @ xn.T], 1)
+        ii = torch.cat([best_i, torch.arange(lo, lo + x.shape[0], device=dev).expand(probe.numel(), -1)], 1)
+        top = torch.topk(sc, k, dim=1)
+        best_s, best_i = top.values, torch.gather(ii, 1, top.indices)
+        lo += x.shape[0]
+        del x, xn, sc, ii
+    exact_ids = best_i.cpu().numpy()
+    recall_exact = float(np.mean([len(set(a.tolist()) & set(e.tolist())) / k for a, e in zip(got, exact_ids)]))
+    centroids, assign = ivf.ivf_export(nlist)
+    xn_host = np.concatenate([R.normalize_rows(blk) for blk in host_blocks])
+    del host_blocks
+    _, ref_ids = R.ivf_search(xn_host, R.normalize_rows(qp.cpu().numpy()), centroids, assign, k, nprobe)
+    parity = float(np.mean(got == ref_ids))
+    del xn_host
+    # ---- the flat scan on the same data, for the QPS comparison only
+    flat = build_clustered(ctx, args.rows, dev, centres, INDEX_FLAT, 0)
+    cf = torch.empty((b, k), device=dev); jf = torch.empty((b, k), dtype=torch.int64, device=dev)
+    flat_ms = timed(lambda: flat.search_device(q.data_ptr(), b, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
+    ivf_bytes = args.rows * D * 2                          # every list is probed at B = 1024: one read of the scan copy
     print(json.dumps({"mode": "ivf", "rows": args.rows, "nlist": nlist, "nprobe": nprobe, "batch": b, "train_s": round(train_s, 2),
                       "flat_ms": round(flat_ms, 3), "flat_qps": round(b / flat_ms * 1e3), "ivf_ms": round(ivf_ms, 3),
-                      "ivf_qps": round(b / ivf_ms * 1e3), "recall_at_10_vs_flat": round(hits / (b * k), 4)}), flush=True)
+                      "ivf_qps": round(b / ivf_ms * 1e3), "probe_queries": int(probe.numel()),
+                      "parity_vs_oracle_ivf": round(parity, 4), "recall_at_10_vs_exact": round(recall_exact, 4),
+                      "roofline": {"bound": "hbm", "achieved": round(ivf_bytes / ivf_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(ivf_bytes / ivf_ms / 1e6 / 8000.0, 4), "traffic": None,
+                                   "algorithmic_bytes": ivf_bytes}}), flush=True)
 
 
 def mode_hard(args, ctx, dev):

@@ -229,7 +229,26 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
     const size_t ld = (size_t)p.K * 2;
     const int KS = p.K / 64;
     const int tiles = p.n_tiles * p.t_tiles;
-    const int my_tiles = blockIdx.x < tiles ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // Tile walk.  Workgroups b and b + 8 share an XCD (and its 4 MiB L2): round r hands XCD x the patch
+    // r * 8 + x of 4 weight tiles x 8 token tiles, one tile per workgroup, so the 32 tiles an XCD has in flight
+    // read 12 operand tiles between them (a K slice of all of them is 384 KiB: it stays in that L2) instead of
+    // the ~27 a strided walk touches.  Patches go weight-tile-group first, so the XCDs of one round share token
+    // rows through the Infinity Cache.  Needs a full grid and n_tiles % 4 == 0; otherwise tile = b + r * grid.
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const bool patched = gridDim.x == 256 && (p.n_tiles & 3) == 0;
+    const int NP = p.n_tiles >> 2, TP = (p.t_tiles + 7) >> 3;
+    auto tile_at = [&](int r) -> int {             // linear id of this workgroup's r-th tile, < 0: none (and none later)
+        if (!patched) {
+            const int t = (int)blockIdx.x + r * (int)gridDim.x;
+            return t < tiles ? t : -1;
+        }
+        const int pidx = r * 8 + xcd;
+        if (pidx >= NP * TP) return -1;
+        const int nt = (pidx % NP) * 4 + (lb & 3), tt = (pidx / NP) * 8 + (lb >> 2);
+        return tt < p.t_tiles ? tt * p.n_tiles + nt : -1;
+    };
+    int my_tiles = 0;
+    while (tile_at(my_tiles) >= 0) ++my_tiles;
     const int total = my_tiles * KS;
     if (total == 0) return;
 
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
         off[i] = (unsigned)(r * ld) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
     // issue cursor
-    int i_tile = blockIdx.x, i_ks = 0;
+    int i_round = 0, i_tile = tile_at(0), i_ks = 0;
     auto issue = [&](int s) {
         const int nt = i_tile % p.n_tiles, tt = i_tile / p.n_tiles;
         const char* ws = reinterpret_cast<const char*>(p.W) + (size_t)nt * BNW * ld + (size_t)i_ks * ROWB;
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
         for (int i = 0; i < 4; ++i) lds_dma16(ws + off[i], buf + (wave + 8 * i) * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(xs + off[i], buf + BNW * ROWB + (wave + 8 * i) * 1024);
-        if (++i_ks == KS) { i_ks = 0; i_tile += gridDim.x; }
+        if (++i_ks == KS) { i_ks = 0; i_tile = tile_at(++i_round); }
     };
 
     f32x4 acc[FM][FN];
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    int tile = blockIdx.x, ks = 0;
+    int round = 0, tile = tile_at(0), ks = 0;
     for (int s = 0; s < total; ++s) {
         const bool more = s + 1 < total;
         if (more) issue(s + 1);
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
                     store_b64_asm(reinterpret_cast<bf16_t*>(p.out) + o, w2);
                 }
             }
-            tile += gridDim.x;
+            tile = tile_at(++round);
             stored = true;
         }
         // next K step landed.  After an epilogue the FM * FN = 32 stores just issued are younger than its
@@ -823,12 +842,38 @@ __device__ __forceinline__ void lds_tr_wait8(u32x2 (&x)[8]) {
                  : "memory");
 }
 
-// NW waves = NW * 16 query rows per workgroup: 4 for short sequences, 8 (128 queries share every K/V tile)
-// from 128 tokens on.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens,
+// reductions over the four lane groups g of a query column c (lanes c, c + 16, c + 32, c + 48): two lane-swap
+// instructions of gfx950 (v_permlane16_swap / v_permlane32_swap, VALU) instead of two trips through the LDS crossbar
+__device__ __forceinline__ float xg_max(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xg_sum(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// NW waves x NQ blocks of 16 query rows per wave = NW * NQ * 16 query rows per workgroup: 64 for short sequences,
+// 128 from 128 tokens on (8 waves x 1 block; from 256 tokens on 4 waves x 2 blocks).  A wave's NQ blocks share every K
+// fragment and every transposed V fragment it reads from LDS, so LDS traffic per MFMA halves with NQ = 2.
+//
+// Per 64-key tile and query block: S^T[key][q] = K Q^T (8 MFMAs) leaves the scores of query c in lane (g, c);
+// the softmax runs there in base 2 -- t = s * (log2 e / 8), p = exp2(t - m), one v_mul, one v_sub and one
+// v_exp per score; keys are masked only in the last, partial tile -- and its probabilities are, as they stand
+// in the accumulators, the B operand of O^T[d][q] += V^T P^T (8 MFMAs, A operand = the transposed V reads).
+// With O transposed a lane holds output columns of ITS OWN query: the rescale by alpha and the final 1 / l
+// need no cross-lane traffic, and a lane stores 4 consecutive output features at a time.
+template <int NW, int NQ, int MINW = 1>
+__global__ __launch_bounds__(NW * 64, MINW) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens,
                                                            bf16_t* __restrict__ ctx, int S, int H, int heads) {
-    constexpr int QB = NW * 16;
+    constexpr int QB = NW * NQ * 16;
+    constexpr float SCALE_LOG2E = 0.125f * 1.4426950408889634f;        // 1 / sqrt(64) folded into the base-2 exponent
     __shared__ __attribute__((aligned(16))) char sKV[2][2 * 64 * ROWB];    // [buffer][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -842,19 +887,26 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     const size_t ld = (size_t)3 * H * 2;             // bytes per token row of qkv
     const char* base = reinterpret_cast<const char*>(qkv) + (size_t)seq * S * ld + (size_t)head * 64 * 2;
 
-    // Q^T fragments of this wave's 16 query rows (B operand: lane (g,c) holds Q[q = c][d = kk*32 + g*8 ..+8))
-    const int q_row = qb * QB + wave * 16 + c;
-    bf16x8 qf[2];
-    {
+    // Q fragments of this wave's NQ x 16 query rows (lane (g, c) holds Q[q = c][d = kk*32 + g*8 .. +8))
+    const int q_base = qb * QB + wave * (NQ * 16);
+    bf16x8 qf[NQ][2];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int q_row = q_base + n * 16 + c;
         const int qr = q_row < S ? q_row : S - 1;
         const char* qp = base + (size_t)qr * ld;
-        qf[0] = *reinterpret_cast<const bf16x8*>(qp + (0 * 32 + g * 8) * 2);
-        qf[1] = *reinterpret_cast<const bf16x8*>(qp + (1 * 32 + g * 8) * 2);
+        qf[n][0] = *reinterpret_cast<const bf16x8*>(qp + (0 * 32 + g * 8) * 2);
+        qf[n][1] = *reinterpret_cast<const bf16x8*>(qp + (1 * 32 + g * 8) * 2);
     }
-    float m = -INFINITY, l = 0.f;                    // running max / sum of query row c
-    f32x4 o[4];                                      // O: col = d (dj*16 + c), row = query g*4 + r
+    float m[NQ], l[NQ];                              // running max (scaled, base-2 domain) / sum of query c
+    f32x4 o[NQ][4];                                  // O^T: row d = dj*16 + g*4 + r, column = query c
 #pragma unroll
-    for (int dj = 0; dj < 4; ++dj) o[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NQ; ++n) {
+        m[n] = -INFINITY;
+        l[n] = 0.f;
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj) o[n][dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // K/V tiles are double buffered: tile t + 1 is fetched while tile t is used (one barrier per tile)
     auto issue_kv = [&](int kv0, int buf) {
@@ -871,60 +923,67 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
         if (kv0 + 64 < len) issue_kv(kv0 + 64, buf ^ 1);
         const char* sK = sKV[buf];
         const char* sV = sKV[buf] + 64 * ROWB;
-        // S^T[key][q] = sum_d K[key][d] Q[q][d]
-        f32x4 st[4];
+        // S^T[key][q] = sum_d K[key][d] Q[q][d]: every K fragment feeds all NQ query blocks
+        f32x4 st[NQ][4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            st[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x8 k0 = frag(sK, kf * 16 + c, g), k1 = frag(sK, kf * 16 + c, 4 + g);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(sK, kf * 16 + c, kk * 4 + g), qf[kk], st[kf], 0, 0, 0);
-        }
-        // scale, mask, online softmax for query row c (keys: kf*16 + g*4 + r)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + kf * 16 + g * 4 + r;
-                const float s = key < len ? st[kf][r] * 0.125f : -INFINITY;
-                st[kf][r] = s;
-                mx = fmaxf(mx, s);
+            for (int n = 0; n < NQ; ++n) {
+                st[n][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[n][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st[n][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[n][1], st[n][kf], 0, 0, 0);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);            // finite: key kv0 < len is never masked
-        const float alpha = __expf(m - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(st[kf][r] - m_new);
-                st[kf][r] = pv;
-                psum += pv;
-            }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l = l * alpha + psum;
-        m = m_new;
-        // rescale O rows (query g*4 + r) by that query's alpha (held by lane q = g*4 + r)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a_q = __shfl(alpha, g * 4 + r, 64);
-#pragma unroll
-            for (int dj = 0; dj < 4; ++dj) o[dj][r] *= a_q;
         }
-        // O += P V : A operand = P straight from the S^T accumulators (k slot j of lane group g
-        // = key 16*(2*kk2 + (j>>2)) + 4*g + (j&3)); B operand = V by transposed LDS reads
+        const bool partial = kv0 + 64 > len;         // wave-uniform: only the last tile of a sequence masks keys
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            // scaled scores of query c (keys kf*16 + g*4 + r) as four 4-vectors: the multiplies, the subtraction of
+            // the maximum and the sums below are packed fp32 instructions (two scores per lane per instruction);
+            // the products are canonical numbers, so the maxima need no NaN quieting
+            f32x4 t[4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) t[kf] = st[n][kf] * SCALE_LOG2E;
+            if (partial) {
+                asm volatile("; tail tile: mask keys >= len" ::);        // keeps this a branch (it is taken once per sequence)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + kf * 16 + g * 4 + r >= len) t[kf][r] = -INFINITY;
+            }
+            const f32x4 mv = __builtin_elementwise_max(__builtin_elementwise_max(t[0], t[1]), __builtin_elementwise_max(t[2], t[3]));
+            const float mx = xg_max(fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3])));
+            const float m_new = fmaxf(m[n], mx);     // finite: key kv0 < len is never masked
+            const float alpha = __builtin_amdgcn_exp2f(m[n] - m_new);
+            // p = exp2(s * c - m): one packed fma on the raw scores (masked ones come from t: they are -inf there)
+            const f32x4 cv = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E};
+            const f32x4 nm = {-m_new, -m_new, -m_new, -m_new};
+            if (partial) {
+                asm volatile("; tail tile: exponents from the masked scores" ::);
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf) t[kf] = t[kf] + nm;
+            } else {
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf) t[kf] = __builtin_elementwise_fma(st[n][kf], cv, nm);
+            }
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[kf][r] = __builtin_amdgcn_exp2f(t[kf][r]);
+                st[n][kf] = t[kf];
+            }
+            const f32x4 sv = (t[0] + t[1]) + (t[2] + t[3]);
+            const float psum = xg_sum((sv[0] + sv[1]) + (sv[2] + sv[3]));
+            l[n] = l[n] * alpha + psum;
+            m[n] = m_new;
+            // O^T columns are this lane's own query: rescale in place
+#pragma unroll
+            for (int dj = 0; dj < 4; ++dj) o[n][dj] *= alpha;
+        }
+        // O^T += V^T P^T : A operand = V by transposed LDS reads (k slot j of lane group g = key
+        // 16*(2*kk2 + (j>>2)) + 4*g + (j&3), feature dj*16 + c), B operand = P straight from the S^T accumulators
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
-            bf16x8 pa;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bf16_t hb = f32_to_bf16(st[2 * kk2 + (j >> 2)][j & 3]);
-                pa[j] = __builtin_bit_cast(__bf16, hb);
-            }
             // lane (g, c = 4*qq + pp) supplies row qq of each 4-key block, columns dj*16 + 4*pp ..;
             // the eight transposed reads of this half go out together and are waited for once
             u32x2 vt[8];
@@ -936,25 +995,40 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
                 vt[2 * dj] = lds_tr_b64_issue(sV + key_lo * ROWB + ((chunk ^ ((key_lo >> 1) & 7)) << 4) + 8 * (pp & 1));
                 vt[2 * dj + 1] = lds_tr_b64_issue(sV + key_hi * ROWB + ((chunk ^ ((key_hi >> 1) & 7)) << 4) + 8 * (pp & 1));
             }
+            bf16x8 pb[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                const u32x4 pk = {pack_bf16x2(st[n][2 * kk2][0], st[n][2 * kk2][1]), pack_bf16x2(st[n][2 * kk2][2], st[n][2 * kk2][3]),
+                                  pack_bf16x2(st[n][2 * kk2 + 1][0], st[n][2 * kk2 + 1][1]),
+                                  pack_bf16x2(st[n][2 * kk2 + 1][2], st[n][2 * kk2 + 1][3])};
+                pb[n] = __builtin_bit_cast(bf16x8, pk);
+            }
             lds_tr_wait8(vt);
 #pragma unroll
             for (int dj = 0; dj < 4; ++dj) {
                 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
                 const u32x4 packed = {vt[2 * dj].x, vt[2 * dj].y, vt[2 * dj + 1].x, vt[2 * dj + 1].y};
-                const bf16x8 vb = __builtin_bit_cast(bf16x8, packed);
-                o[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dj], 0, 0, 0);
+                const bf16x8 va = __builtin_bit_cast(bf16x8, packed);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) o[n][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[n], o[n][dj], 0, 0, 0);
             }
         }
     }
-    // normalise and store: O[q = g*4 + r][d = dj*16 + c]
+    // normalise and store: lane (g, c) holds O[q = c][d = dj*16 + g*4 + r], four consecutive features per dj
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float l_q = __shfl(l, g * 4 + r, 64);
-        const int q = qb * QB + wave * 16 + g * 4 + r;
+    for (int n = 0; n < NQ; ++n) {
+        const int q = q_base + n * 16 + c;
         if (q < len) {
-            bf16_t* dst = ctx + ((size_t)seq * S + q) * H + head * 64;
+            const float inv = 1.0f / l[n];
+            bf16_t* dst = ctx + ((size_t)seq * S + q) * H + head * 64 + g * 4;
 #pragma unroll
-            for (int dj = 0; dj < 4; ++dj) dst[dj * 16 + c] = f32_to_bf16(o[dj][r] / l_q);
+            for (int dj = 0; dj < 4; ++dj) {
+                uint2 w;
+                w.x = pack_bf16x2(o[n][dj][0] * inv, o[n][dj][1] * inv);
+                w.y = pack_bf16x2(o[n][dj][2] * inv, o[n][dj][3] * inv);
+                *reinterpret_cast<uint2*>(dst + dj * 16) = w;
+            }
         }
     }
 }
@@ -1229,8 +1303,8 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
                        enc->type.as<bf16_t>(), enc->emb_g.as<float>(), enc->emb_b.as<float>(), enc->pre.as<float>(),
                        enc->x.as<bf16_t>(), T, S, H, c.vocab_size, c.ln_eps);
     SQE_HIP(hipGetLastError());
-    const int att_nw = S >= 128 ? 8 : 4;
-    const int qblocks = (S + att_nw * 16 - 1) / (att_nw * 16);
+    const int att_qb = S >= 256 ? 256 : S >= 128 ? 128 : 64;      // query rows per attention workgroup
+    const int qblocks = (S + att_qb - 1) / att_qb;
     for (int l = 0; l < c.layers; ++l) {
         sqe_layer& L = *enc->layers[l];
         GemmArgs a;
@@ -1239,11 +1313,18 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
         a.W = L.w_qkv.as<bf16_t>(); a.X = enc->x.as<bf16_t>(); a.bias = L.b_qkv.as<float>(); a.out = enc->qkv.p; a.N = 3 * H; a.K = H;
         SQE_TRY(launch_gemm<EPI_BIAS>(a, t_pad, cus, st));
         // E3: attention
-        if (att_nw == 8)
-            hipLaunchKernelGGL(attention_kernel<8>, dim3(B * c.heads * qblocks), dim3(512), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
+        static const bool att_wide = [] { const char* e = knob_env("SQE_ATT_WIDE"); return e && e[0] == '1'; }();   // knobs build: A/B
+        if (att_qb == 256 && att_wide)
+            hipLaunchKernelGGL((attention_kernel<8, 2, 4>), dim3(B * c.heads * qblocks), dim3(512), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
+                               enc->att.as<bf16_t>(), S, H, c.heads);
+        else if (att_qb == 256)      // 4 waves x 2 blocks: 128 query rows per workgroup, three workgroups per CU
+            hipLaunchKernelGGL((attention_kernel<4, 2, 3>), dim3(B * c.heads * ((S + 127) / 128)), dim3(256), 0, st, enc->qkv.as<bf16_t>(),
+                               lens_dev, enc->att.as<bf16_t>(), S, H, c.heads);
+        else if (att_qb == 128)
+            hipLaunchKernelGGL((attention_kernel<8, 1>), dim3(B * c.heads * qblocks), dim3(512), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
                                enc->att.as<bf16_t>(), S, H, c.heads);
         else
-            hipLaunchKernelGGL(attention_kernel<4>, dim3(B * c.heads * qblocks), dim3(256), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
+            hipLaunchKernelGGL((attention_kernel<4, 1>), dim3(B * c.heads * qblocks), dim3(256), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
                                enc->att.as<bf16_t>(), S, H, c.heads);
         SQE_HIP(hipGetLastError());
         // E4: output projection + residual, LayerNorm
