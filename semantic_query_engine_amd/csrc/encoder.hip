@@ -25,6 +25,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <stdlib.h>
@@ -92,6 +93,25 @@ __device__ __forceinline__ float gelu_erf(float v) {
     poly = fmaf(poly, t, 0.254829592f);
     const float e = 1.0f - poly * t * __expf(-x * x);          // erf(|v| / sqrt 2)
     return 0.5f * v * (1.0f + copysignf(e, v));
+}
+
+// The same on two values at once: every multiply / fma of the chain is one packed fp32 instruction
+// (v_pk_mul_f32 / v_pk_fma_f32), which halves the instruction count of the GELU epilogue -- the epilogue of the
+// FFN-up GEMM is VALU-issue-bound (no MFMA runs beside it).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    const f32x2 x = {fabsf(v[0]) * 0.70710678118654752f, fabsf(v[1]) * 0.70710678118654752f};
+    const f32x2 den = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, x, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 poly = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 nx2 = x * x * -1.4426950408889634f;                  // exp(-x^2) = exp2(-x^2 log2 e)
+    const f32x2 ex = {__builtin_amdgcn_exp2f(nx2[0]), __builtin_amdgcn_exp2f(nx2[1])};
+    const f32x2 e = __builtin_elementwise_fma(poly * t, -ex, f32x2{1.0f, 1.0f});      // erf(|v| / sqrt 2)
+    const f32x2 es = {copysignf(e[0], v[0]), copysignf(e[1], v[1])};
+    return __builtin_elementwise_fma(es, v * 0.5f, v * 0.5f);          // 0.5 v (1 + erf)
 }
 
 struct GemmArgs {
@@ -341,7 +361,8 @@ __global__ __launch_bounds__(512) void gemm_persistent_kernel(GemmArgs p) {
                         v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
                         v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
                     } else if (EPI == EPI_GELU) {
-                        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+                        const f32x2 g01 = gelu_erf2(f32x2{v0, v1}), g23 = gelu_erf2(f32x2{v2, v3});
+                        v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
                     }
                     // (the pre-LayerNorm sums of EPI_RESID leave as bf16 too: half the bytes written here and
                     // read by the LayerNorm kernel; the small-batch kernels keep fp32 split-K partial sums)
@@ -835,6 +856,13 @@ __device__ __forceinline__ u32x2 lds_tr_b64_issue(const char* addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(v) : "v"(a) : "memory");
     return v;
 }
+// the same read at a compile-time byte offset from a per-lane LDS address (the offset field of the DS instruction)
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr_b64_issue_at(uint32_t lds_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    return v;
+}
 __device__ __forceinline__ void lds_tr_wait8(u32x2 (&x)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
@@ -910,24 +938,36 @@ __global__ __launch_bounds__(NW * 64, MINW) void attention_kernel(const bf16_t* 
 
     // K/V tiles are double buffered: tile t + 1 is fetched while tile t is used (one barrier per tile)
     auto issue_kv = [&](int kv0, int buf) {
-        stage_rows_asm<64, NW>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sKV[buf], wave, lane);                   // K part
-        stage_rows_asm<64, NW>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sKV[buf] + 64 * ROWB, wave, lane);   // V part
+        // (the builtin form: hipcc knows these are loads; through inline asm it has to assume a store that still
+        // reads its address registers and waits on vmcnt before it reuses them -- in the middle of the MFMAs)
+        stage_rows<64, NW>(base + (size_t)kv0 * ld + (size_t)H * 2, ld, sKV[buf], wave, lane);                   // K part
+        stage_rows<64, NW>(base + (size_t)kv0 * ld + (size_t)2 * H * 2, ld, sKV[buf] + 64 * ROWB, wave, lane);   // V part
     };
-    issue_kv(0, 0);
-    int buf = 0;
-    for (int kv0 = 0; kv0 < len; kv0 += 64, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // my pieces of this tile landed, my LDS reads are done
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                                  // everyone's landed; everyone left the other buffer
-        __builtin_amdgcn_sched_barrier(0);
-        if (kv0 + 64 < len) issue_kv(kv0 + 64, buf ^ 1);
-        const char* sK = sKV[buf];
-        const char* sV = sKV[buf] + 64 * ROWB;
+    // Per-lane LDS addresses, computed ONCE: every read of the loop is one of these plus a compile-time offset
+    // (buffer, key block), so no address arithmetic is left in the loop.  The XOR swizzle of a tile row depends
+    // on (row >> 1) & 7 only, which a step of 16 rows (K fragments) or 16 / 32 keys (V blocks) does not change.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)&sKV[0][0];
+    const int ksw = (c >> 1) & 7;
+    const uint32_t kaddr0 = lds0 + c * ROWB + ((g ^ ksw) << 4);              // K fragment, d = g*8 .. (first 32 of 64)
+    const uint32_t kaddr1 = lds0 + c * ROWB + (((4 + g) ^ ksw) << 4);        // d = 32 + g*8 ..
+    uint32_t vaddr[4];                                                       // V^T fragment of feature block dj, key 4g + qq
+    {
+        const int qq = c >> 2, pp = c & 3, key0 = 4 * g + qq, vsw = (key0 >> 1) & 7;
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj)
+            vaddr[dj] = lds0 + 64 * ROWB + key0 * ROWB + (((dj * 2 + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
+    }
+    constexpr int BUFB = 2 * 64 * ROWB;              // bytes per K|V buffer
+
+    // one 64-key tile out of buffer BUF (a compile-time constant: it selects the immediate offsets)
+    auto tile = [&](int kv0, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
         // S^T[key][q] = sum_d K[key][d] Q[q][d]: every K fragment feeds all NQ query blocks
         f32x4 st[NQ][4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            const bf16x8 k0 = frag(sK, kf * 16 + c, g), k1 = frag(sK, kf * 16 + c, 4 + g);
+            const bf16x8 k0 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)(kaddr0 + BUF * BUFB + kf * 16 * ROWB));
+            const bf16x8 k1 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)(kaddr1 + BUF * BUFB + kf * 16 * ROWB));
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
                 st[n][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[n][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -937,22 +977,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void attention_kernel(const bf16_t* 
         const bool partial = kv0 + 64 > len;         // wave-uniform: only the last tile of a sequence masks keys
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
-            // scaled scores of query c (keys kf*16 + g*4 + r) as four 4-vectors: the multiplies, the subtraction of
-            // the maximum and the sums below are packed fp32 instructions (two scores per lane per instruction);
-            // the products are canonical numbers, so the maxima need no NaN quieting
+            // scaled scores of query c (keys kf*16 + g*4 + r); the products are canonical numbers, so the maxima
+            // need no NaN quieting and pair up into v_max3
             f32x4 t[4];
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) t[kf] = st[n][kf] * SCALE_LOG2E;
             if (partial) {
-                asm volatile("; tail tile: mask keys >= len" ::);        // keeps this a branch (it is taken once per sequence)
+                int lenx = len;
+                asm volatile("; tail tile: mask keys >= len" : "+s"(lenx));   // opaque: nothing of this block is hoisted
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kv0 + kf * 16 + g * 4 + r >= len) t[kf][r] = -INFINITY;
+                        if (kv0 + kf * 16 + g * 4 + r >= lenx) t[kf][r] = -INFINITY;
             }
-            const f32x4 mv = __builtin_elementwise_max(__builtin_elementwise_max(t[0], t[1]), __builtin_elementwise_max(t[2], t[3]));
-            const float mx = xg_max(fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3])));
+            float mx = fmaxf(fmaxf(t[0][0], t[0][1]), t[0][2]);
+            mx = fmaxf(fmaxf(mx, t[0][3]), t[1][0]);
+            mx = fmaxf(fmaxf(mx, t[1][1]), t[1][2]);
+            mx = fmaxf(fmaxf(mx, t[1][3]), t[2][0]);
+            mx = fmaxf(fmaxf(mx, t[2][1]), t[2][2]);
+            mx = fmaxf(fmaxf(mx, t[2][3]), t[3][0]);
+            mx = fmaxf(fmaxf(mx, t[3][1]), t[3][2]);
+            mx = xg_max(fmaxf(mx, t[3][3]));
             const float m_new = fmaxf(m[n], mx);     // finite: key kv0 < len is never masked
             const float alpha = __builtin_amdgcn_exp2f(m[n] - m_new);
             // p = exp2(s * c - m): one packed fma on the raw scores (masked ones come from t: they are -inf there)
@@ -982,26 +1028,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void attention_kernel(const bf16_t* 
         }
         // O^T += V^T P^T : A operand = V by transposed LDS reads (k slot j of lane group g = key
         // 16*(2*kk2 + (j>>2)) + 4*g + (j&3), feature dj*16 + c), B operand = P straight from the S^T accumulators
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) {
-            // lane (g, c = 4*qq + pp) supplies row qq of each 4-key block, columns dj*16 + 4*pp ..;
+        auto pv_half = [&](auto kk2_tag) {
+            constexpr int KK2 = decltype(kk2_tag)::value;
+            constexpr int LO = BUF * BUFB + 32 * KK2 * ROWB, HI = LO + 16 * ROWB;
             // the eight transposed reads of this half go out together and are waited for once
             u32x2 vt[8];
-#pragma unroll
-            for (int dj = 0; dj < 4; ++dj) {
-                const int qq = c >> 2, pp = c & 3;
-                const int chunk = dj * 2 + (pp >> 1);
-                const int key_lo = 16 * (2 * kk2) + 4 * g + qq, key_hi = 16 * (2 * kk2 + 1) + 4 * g + qq;
-                vt[2 * dj] = lds_tr_b64_issue(sV + key_lo * ROWB + ((chunk ^ ((key_lo >> 1) & 7)) << 4) + 8 * (pp & 1));
-                vt[2 * dj + 1] = lds_tr_b64_issue(sV + key_hi * ROWB + ((chunk ^ ((key_hi >> 1) & 7)) << 4) + 8 * (pp & 1));
-            }
+            vt[0] = lds_tr_b64_issue_at<LO>(vaddr[0]); vt[1] = lds_tr_b64_issue_at<HI>(vaddr[0]);
+            vt[2] = lds_tr_b64_issue_at<LO>(vaddr[1]); vt[3] = lds_tr_b64_issue_at<HI>(vaddr[1]);
+            vt[4] = lds_tr_b64_issue_at<LO>(vaddr[2]); vt[5] = lds_tr_b64_issue_at<HI>(vaddr[2]);
+            vt[6] = lds_tr_b64_issue_at<LO>(vaddr[3]); vt[7] = lds_tr_b64_issue_at<HI>(vaddr[3]);
             bf16x8 pb[NQ];
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
                 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-                const u32x4 pk = {pack_bf16x2(st[n][2 * kk2][0], st[n][2 * kk2][1]), pack_bf16x2(st[n][2 * kk2][2], st[n][2 * kk2][3]),
-                                  pack_bf16x2(st[n][2 * kk2 + 1][0], st[n][2 * kk2 + 1][1]),
-                                  pack_bf16x2(st[n][2 * kk2 + 1][2], st[n][2 * kk2 + 1][3])};
+                const u32x4 pk = {pack_bf16x2(st[n][2 * KK2][0], st[n][2 * KK2][1]), pack_bf16x2(st[n][2 * KK2][2], st[n][2 * KK2][3]),
+                                  pack_bf16x2(st[n][2 * KK2 + 1][0], st[n][2 * KK2 + 1][1]),
+                                  pack_bf16x2(st[n][2 * KK2 + 1][2], st[n][2 * KK2 + 1][3])};
                 pb[n] = __builtin_bit_cast(bf16x8, pk);
             }
             lds_tr_wait8(vt);
@@ -1013,7 +1055,25 @@ __global__ __launch_bounds__(NW * 64, MINW) void attention_kernel(const bf16_t* 
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) o[n][dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[n], o[n][dj], 0, 0, 0);
             }
-        }
+        };
+        pv_half(std::integral_constant<int, 0>{});
+        pv_half(std::integral_constant<int, 1>{});
+    };
+    auto tile_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // my pieces of this tile landed, my LDS reads are done
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                  // everyone's landed; everyone left the other buffer
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    issue_kv(0, 0);
+    for (int kv0 = 0; kv0 < len; kv0 += 128) {       // two tiles per trip: the buffer index is a compile-time constant
+        tile_sync();
+        if (kv0 + 64 < len) issue_kv(kv0 + 64, 1);
+        tile(kv0, std::integral_constant<int, 0>{});
+        if (kv0 + 64 >= len) break;
+        tile_sync();
+        if (kv0 + 128 < len) issue_kv(kv0 + 128, 0);
+        tile(kv0 + 64, std::integral_constant<int, 1>{});
     }
     // normalise and store: lane (g, c) holds O[q = c][d = dj*16 + g*4 + r], four consecutive features per dj
 #pragma unroll
@@ -1313,19 +1373,22 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
         a.W = L.w_qkv.as<bf16_t>(); a.X = enc->x.as<bf16_t>(); a.bias = L.b_qkv.as<float>(); a.out = enc->qkv.p; a.N = 3 * H; a.K = H;
         SQE_TRY(launch_gemm<EPI_BIAS>(a, t_pad, cus, st));
         // E3: attention
-        static const bool att_wide = [] { const char* e = knob_env("SQE_ATT_WIDE"); return e && e[0] == '1'; }();   // knobs build: A/B
-        if (att_qb == 256 && att_wide)
-            hipLaunchKernelGGL((attention_kernel<8, 2, 4>), dim3(B * c.heads * qblocks), dim3(512), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
-                               enc->att.as<bf16_t>(), S, H, c.heads);
+        static const int att_form = [] { const char* e = knob_env("SQE_ATT_FORM"); return e ? atoi(e) : 0; }();   // knobs build: A/B
+        const bf16_t* qkvp = enc->qkv.as<bf16_t>();
+        bf16_t* attp = enc->att.as<bf16_t>();
+        const int nsh = B * c.heads;
+        if (att_qb == 256 && att_form == 1)
+            hipLaunchKernelGGL((attention_kernel<8, 2, 4>), dim3(nsh * qblocks), dim3(512), 0, st, qkvp, lens_dev, attp, S, H, c.heads);
+        else if (att_qb == 256 && att_form == 2)
+            hipLaunchKernelGGL((attention_kernel<8, 1>), dim3(nsh * ((S + 127) / 128)), dim3(512), 0, st, qkvp, lens_dev, attp, S, H, c.heads);
+        else if (att_qb == 256 && att_form == 3)
+            hipLaunchKernelGGL((attention_kernel<4, 1>), dim3(nsh * ((S + 63) / 64)), dim3(256), 0, st, qkvp, lens_dev, attp, S, H, c.heads);
         else if (att_qb == 256)      // 4 waves x 2 blocks: 128 query rows per workgroup, three workgroups per CU
-            hipLaunchKernelGGL((attention_kernel<4, 2, 3>), dim3(B * c.heads * ((S + 127) / 128)), dim3(256), 0, st, enc->qkv.as<bf16_t>(),
-                               lens_dev, enc->att.as<bf16_t>(), S, H, c.heads);
+            hipLaunchKernelGGL((attention_kernel<4, 2, 3>), dim3(nsh * ((S + 127) / 128)), dim3(256), 0, st, qkvp, lens_dev, attp, S, H, c.heads);
         else if (att_qb == 128)
-            hipLaunchKernelGGL((attention_kernel<8, 1>), dim3(B * c.heads * qblocks), dim3(512), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
-                               enc->att.as<bf16_t>(), S, H, c.heads);
+            hipLaunchKernelGGL((attention_kernel<8, 1>), dim3(nsh * qblocks), dim3(512), 0, st, qkvp, lens_dev, attp, S, H, c.heads);
         else
-            hipLaunchKernelGGL((attention_kernel<4, 1>), dim3(B * c.heads * qblocks), dim3(256), 0, st, enc->qkv.as<bf16_t>(), lens_dev,
-                               enc->att.as<bf16_t>(), S, H, c.heads);
+            hipLaunchKernelGGL((attention_kernel<4, 1>), dim3(nsh * qblocks), dim3(256), 0, st, qkvp, lens_dev, attp, S, H, c.heads);
         SQE_HIP(hipGetLastError());
         // E4: output projection + residual, LayerNorm
         a.W = L.w_o.as<bf16_t>(); a.X = enc->att.as<bf16_t>(); a.bias = L.b_o.as<float>(); a.resid = enc->x.as<bf16_t>();
