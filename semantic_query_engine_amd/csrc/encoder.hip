@@ -401,6 +401,256 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
     return SQE_OK;
 }
 
+// Large-batch form, ping-pong schedule (the schedule of the flat scan, scan_pp.hip, with an epilogue where the
+// scan has its filter): 256 x 256 tiles, PERSISTENT workgroups, K in 32-wide half-steps through a 4-stage LDS
+// ring (three half-steps of DMA in flight instead of the one 64-wide step of gemm_persistent_kernel), the
+// two waves of a SIMD alternating between a compute phase (32 MFMAs on registers) and a memory phase (LDS-DMA
+// issue, 12 ds_read_b128), one s_barrier per phase.  G0 (waves 0-3) runs one phase ahead of G1 (waves 4-7):
+//     G0: .. CMP(e,last) | EPI(e) MEM(e+1,0) | CMP(e+1,0)        | MEM(e+1,1) ..
+//     G1: .. MEM(e,last) | CMP(e,last)       | EPI(e) MEM(e+1,0) | CMP(e+1,0) ..
+// A group's epilogue (VALU + stores) runs beside the OTHER group's compute phase, at the head of its own next
+// memory phase, when its operand registers are dead (no spills) -- the 8-wave epilogue of gemm_persistent_kernel
+// runs with the matrix pipe idle.  The first compute phase of a tile takes a zero C operand (no VALU clears).
+// The epilogue's 32 stores per wave are fire-and-forget: the memory phase it shares and the next one wait with
+// vmcnt(40), which leaves them in flight together with the two younger half-steps of DMA (vmcnt retires in
+// issue order).
+namespace gpp {
+constexpr int HALF_K = 32, LINE_BYTES = 128, OPER_BYTES = 128 * LINE_BYTES, STAGE_BYTES = 2 * OPER_BYTES, NSTAGE = 4;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;       // 128 KiB
+typedef bf16x8 AOps[8];
+typedef bf16x8 BOps[4];
+struct Cursor { int e, h; const char* a; const char* b; };
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#define GPP_BARRIER()                          \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+template <bool FIRST>
+__device__ __forceinline__ void cmp_phase(f32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm], b[fn], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn], 0, 0, 0);
+}
+}  // namespace gpp
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
+    using namespace gpp;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2, wm = wave >> 2, wn = wave & 3;
+    const size_t ld = (size_t)p.K * 2;
+    const int HS = p.K / HALF_K;
+    const int tiles = p.n_tiles * p.t_tiles;
+    // tile walk: as gemm_persistent_kernel (XCD-aware 4 x 8 patches on a full grid)
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const bool patched = gridDim.x == 256 && (p.n_tiles & 3) == 0;
+    const int NP = p.n_tiles >> 2, TP = (p.t_tiles + 7) >> 3;
+    auto tile_at = [&](int r) -> int {
+        if (!patched) {
+            const int t = (int)blockIdx.x + r * (int)gridDim.x;
+            return t < tiles ? t : -1;
+        }
+        const int pidx = r * 8 + xcd;
+        if (pidx >= NP * TP) return -1;
+        const int nt = (pidx % NP) * 4 + (lb & 3), tt = (pidx / NP) * 8 + (lb >> 2);
+        return tt < p.t_tiles ? tt * p.n_tiles + nt : -1;
+    };
+    int my_tiles = 0;
+    while (tile_at(my_tiles) >= 0) ++my_tiles;
+    const int J = my_tiles * HS;
+    if (J == 0) return;
+
+    // per-lane DMA source offsets (piece t covers LDS lines 8t .. 8t+7; line L holds the slices of tile rows L
+    // and L + 128, chunk positions XOR-swizzled by (L >> 1) & 7) and operand read offsets: as scan_pp.hip
+    unsigned off0, off1, rdA, rdB;
+    {
+        const int line = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((line >> 1) & 7);
+        const int row = line + 128 * (c >> 2);
+        off0 = (unsigned)(row * ld) + (c & 3) * 16;
+        off1 = off0 + (unsigned)(64 * ld);
+        const int r = lane & 15, cq = lane >> 4, sw = (r >> 1) & 7;
+        rdA = (unsigned)(r * LINE_BYTES + (((wm * 4 + cq) ^ sw) << 4));
+        rdB = (unsigned)(((wn & 1) * 64 + r) * LINE_BYTES + ((((wn >> 1) * 4 + cq) ^ sw) << 4));
+    }
+    auto seat = [&](Cursor& c) {                      // operand tiles of entry c.e
+        const int t = tile_at(c.e);
+        const int nt = t % p.n_tiles, tt = t / p.n_tiles;
+        c.a = reinterpret_cast<const char*>(p.W) + (size_t)nt * 256 * ld;
+        c.b = reinterpret_cast<const char*>(p.X) + (size_t)tt * 256 * ld;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.h == HS) {
+            c.h = 0;
+            if (++c.e < my_tiles) seat(c);
+        }
+    };
+    auto issue = [&](const Cursor& c, int stage) {
+        char* st = smem + stage * STAGE_BYTES;
+        const char* as = c.a + c.h * (HALF_K * 2);
+        const char* bs = c.b + c.h * (HALF_K * 2);
+        glds16(as + off0, st + wave * 1024);
+        glds16(as + off1, st + (wave + 8) * 1024);
+        glds16(bs + off0, st + OPER_BYTES + wave * 1024);
+        glds16(bs + off1, st + OPER_BYTES + (wave + 8) * 1024);
+    };
+    Cursor rd{0, 0, nullptr, nullptr}, dm{0, 0, nullptr, nullptr};
+    seat(rd);
+    seat(dm);
+    int post_epi = 0;                                 // memory phases that still have this wave's epilogue stores in flight
+
+    f32x4 acc[8][4];
+    AOps a;
+    BOps b;
+    auto mem_phase = [&](int j) {
+        const bool more = j + 3 < J;
+        if (more) issue(dm, (j + 3) & 3);
+        const char* st = smem + (j & 3) * STAGE_BYTES;
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + rdA + fm * 2048);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + rdB + fn * 2048);
+        // retire the DMA of half-step j + 1; j + 2 and j + 3 stay in flight, and so do the 32 epilogue stores for
+        // the two memory phases after an epilogue (they are younger than the half-step that has to land)
+        if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (post_epi > 0) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        if (post_epi > 0) --post_epi;
+        advance(rd);
+        if (more) advance(dm);
+    };
+    auto epilogue = [&](int e) {
+        const int t = tile_at(e);
+        const int nt = t % p.n_tiles, tt = t / p.n_tiles;
+        const int n0 = nt * 256, t0 = tt * 256;
+        // The loads an epilogue needs are issued before its first store (a load hipcc can see makes it wait for
+        // everything older, the stores included).  EPI_RESID reads 64 VGPRs of residual per wave: it goes in two
+        // halves of four feature blocks, so that the kernel keeps its accumulators and the residual in registers.
+        constexpr int HALVES = EPI == EPI_RESID ? 2 : 1;
+        constexpr int IB = 8 / HALVES;
+#pragma unroll
+        for (int half = 0; half < HALVES; ++half) {
+            uint2 res[EPI == EPI_RESID ? IB : 1][EPI == EPI_RESID ? 4 : 1];
+            float4 bias4[IB];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int i = half * IB + ii;
+                const int n = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+                bias4[ii] = *reinterpret_cast<const float4*>(p.bias + n);
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
+                        res[EPI == EPI_RESID ? ii : 0][EPI == EPI_RESID ? j : 0] =
+                            *reinterpret_cast<const uint2*>(p.resid + (size_t)tk * p.N + n);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int i = half * IB + ii;
+                const int n = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+                const float4 b4 = bias4[ii];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
+                    float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+                    const size_t o = (size_t)tk * p.N + n;
+                    if (EPI == EPI_RESID) {
+                        const uint2 r2 = res[EPI == EPI_RESID ? ii : 0][EPI == EPI_RESID ? j : 0];
+                        v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
+                        v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
+                    } else if (EPI == EPI_GELU) {
+                        const f32x2 g01 = gelu_erf2(f32x2{v0, v1}), g23 = gelu_erf2(f32x2{v2, v3});
+                        v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+                    }
+                    uint2 w2;
+                    w2.x = pack_bf16x2(v0, v1);
+                    w2.y = pack_bf16x2(v2, v3);
+                    store_b64_asm(reinterpret_cast<bf16_t*>(p.out) + o, w2);
+                }
+            }
+        }
+        post_epi = 2;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: half-steps 0, 1, 2
+    for (int s = 0; s < 3 && s < J; ++s) {
+        issue(dm, s);
+        advance(dm);
+    }
+    __syncthreads();                       // vmcnt(0) + barrier: prologue landed
+
+    int j = 0;
+    if (group == 0) {
+        mem_phase(0);
+        GPP_BARRIER();
+        for (int e = 0; e < my_tiles; ++e) {
+            cmp_phase<true>(acc, a, b);
+            GPP_BARRIER();
+            mem_phase(j + 1);
+            GPP_BARRIER();
+            ++j;
+            for (int h = 1; h < HS - 1; ++h) {
+                cmp_phase<false>(acc, a, b);
+                GPP_BARRIER();
+                mem_phase(j + 1);
+                GPP_BARRIER();
+                ++j;
+            }
+            cmp_phase<false>(acc, a, b);
+            GPP_BARRIER();
+            epilogue(e);
+            if (j + 1 < J) mem_phase(j + 1);
+            GPP_BARRIER();
+            ++j;
+        }
+    } else {
+        GPP_BARRIER();
+        for (int e = 0; e < my_tiles; ++e) {
+            if (e > 0) epilogue(e - 1);
+            mem_phase(j);
+            GPP_BARRIER();
+            cmp_phase<true>(acc, a, b);
+            GPP_BARRIER();
+            ++j;
+            for (int h = 1; h < HS; ++h) {
+                mem_phase(j);
+                GPP_BARRIER();
+                cmp_phase<false>(acc, a, b);
+                GPP_BARRIER();
+                ++j;
+            }
+        }
+        epilogue(my_tiles - 1);
+    }
+}
+
+template <int EPI>
+int launch_gemm_pp(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, int* splits_out = nullptr) {
+    GemmArgs p = a;
+    p.n_tiles = a.N / 256;
+    p.t_tiles = t_pad / 256;
+    p.splits = 1; p.split_stride = 0;
+    const int tiles = p.n_tiles * p.t_tiles;
+    auto kern = gemm_pp_kernel<EPI>;
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), gpp::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count)), dim3(512), gpp::LDS_BYTES, stream, p);
+    SQE_HIP(hipGetLastError());
+    if (EPI == EPI_RESID && splits_out) *splits_out = 0;      // 0 partial sums: one bf16 row
+    return SQE_OK;
+}
+
 // Small-batch form: 128 x 128 tiles, 4-stage LDS ring (3 K steps of DMA in flight, counted waits, pieces
 // issued through lds_dma16 so hipcc adds no vmcnt(0) of its own), optional split-K.  With a few
 // hundred tokens a GEMM has fewer tiles than the chip has CUs and every K step of the two-stage kernel
@@ -658,6 +908,8 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
     if (big) {
         static const bool old_form = [] { const char* e = knob_env("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
+        static const int form = [] { const char* e = knob_env("SQE_ENC_GEMM"); return e ? atoi(e) : 0; }();   // knobs build: A/B
+        if (!old_form && form == 1 && a.K % 64 == 0) return launch_gemm_pp<EPI>(a, t_pad, cu_count, stream, splits_out);
         if (!old_form) return launch_gemm_persistent<EPI>(a, t_pad, cu_count, stream, splits_out);
         GemmArgs p = a;
         p.splits = 1; p.split_stride = 0; p.t_tiles = 0;
