@@ -9,13 +9,14 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}/p$i -- python3 bench_configs.py --mode encode --batch 64 > /dev/null 2> gpurun_out/pmc_${tag}_p$i.err || echo "pass $i failed"
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("gpurun_out/pmc_${tag}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "sqe::" not in name: continue
-        key = name.split("(")[0].replace("void sqe::(anonymous namespace)::", "").replace("sqe::(anonymous namespace)::", "")
+        m = re.search(r"::(\w+(?:<[^>]*>)?)\(", name)
+        key = m.group(1) if m else name[:60]
         a = acc[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, d in acc.items():
     print(k)
