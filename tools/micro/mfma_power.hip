@@ -1,0 +1,97 @@
+// Sustained MFMA rate under the board's power management, registers only (no LDS, no HBM in the loop):
+// what bf16 throughput the part holds on random operands vs zeros, for the 16x16x32 and 32x32x16 shapes.
+// Build on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_power.hip -o /tmp/mfma_power
+// Run:                   /tmp/mfma_power            (prints one line per variant)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// 8 x 4 fragments of 16x16x32 per wave and trip: 32 MFMAs, 32 * 16*16*32*2 flop = 524288 flop
+__global__ __launch_bounds__(512) void k16(const bf16x8* __restrict__ src, float* __restrict__ out, int trips) {
+    bf16x8 a[8], b[4];
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < 8; ++i) a[i] = src[(i * 64 + lane) & 4095];
+    for (int i = 0; i < 4; ++i) b[i] = src[((8 + i) * 64 + lane) & 4095];
+    f32x4 acc[8][4] = {};
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
+// 4 x 2 fragments of 32x32x16 per wave and trip, two K halves: 16 MFMAs of 32*32*16*2 flop = 524288 flop
+__global__ __launch_bounds__(512) void k32(const bf16x8* __restrict__ src, float* __restrict__ out, int trips) {
+    bf16x8 a[8], b[4];
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < 8; ++i) a[i] = src[(i * 64 + lane) & 4095];
+    for (int i = 0; i < 4; ++i) b[i] = src[((8 + i) * 64 + lane) & 4095];
+    f32x16 acc[4][2] = {};
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i * 2 + h], b[j * 2 + h], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 12345.678f) out[0] = s;
+}
+
+static uint16_t bf16_of(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+    const int trips = argc > 1 ? atoi(argv[1]) : 40000;
+    const int reps = argc > 2 ? atoi(argv[2]) : 8;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    std::vector<uint16_t> h(4096 * 8);
+    bf16x8* src; float* out;
+    CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&out, 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const char* data_names[3] = {"zeros", "gauss(0,1/32)", "gauss, 2 waves/SIMD"};
+    for (int shape = 0; shape < 2; ++shape)
+        for (int data = 0; data < 3; ++data) {
+            srand(7);
+            for (auto& v : h) {
+                float g = 0.f;
+                if (data) { for (int i = 0; i < 12; ++i) g += rand() / (float)RAND_MAX; g = (g - 6.f) / 32.f; }
+                v = bf16_of(g);
+            }
+            CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+            const int threads = data == 2 ? 512 : 256;              // 1 or 2 waves per SIMD, one workgroup per CU
+            const int grid = cus;
+            double best = 0, last = 0;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                if (shape == 0) k16<<<grid, threads>>>(src, out, trips); else k32<<<grid, threads>>>(src, out, trips);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                const double flop = (double)grid * (threads / 64) * trips * 524288.0;
+                last = flop / (ms * 1e-3) / 1e12;
+                if (last > best) best = last;
+            }
+            printf("{\"shape\": \"%s\", \"data\": \"%s\", \"cus\": %d, \"waves_per_simd\": %d, \"tflops_last\": %.1f, \"tflops_best\": %.1f}\n",
+                   shape ? "32x32x16" : "16x16x32", data_names[data], cus, threads / 256, last, best);
+            fflush(stdout);
+        }
+    return 0;
+}
