@@ -407,7 +407,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
     }
     const int64_t n_rows = idx->n.load();
     const int kp = auto_kp(idx, k);
-    const ScanPlan plan = make_scan_plan(n_rows, B, kp, c->cu_count);
+    const ScanPlan plan = make_scan_plan(n_rows, B, kp, c->cu_count, k);
 
     SQE_TRY(idx->qn.ensure((size_t)B * K * 4));
     SQE_TRY(idx->qb.ensure((size_t)plan.b_pad * idx->pitch));
@@ -447,6 +447,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
         a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
         a.dbg_counters = nullptr;
+        a.q_resid = idx->q_resid.as<float>(); a.db_resid_max = idx->resid_max.as<uint32_t>();   // the k-row bound's eps
         a.collect_thr = nullptr; a.collect_keys = nullptr; a.collect_cnt = nullptr; a.unc_count = nullptr;
         {
             static const bool want = [] { const char* e = knob_env("SQE_DBG"); return e && (atoi(e) & 32); }();   // knobs build only
@@ -472,6 +473,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         sa.q_resid = certify ? idx->q_resid.as<float>() : nullptr;
         sa.db_resid_max = certify ? idx->resid_max.as<uint32_t>() : nullptr;
         sa.unc_count = unc_count; sa.collect_thr = collect_thr;
+        sa.gmax = (n_rows > 0 && plan.gshift >= 0) ? idx->gmax.as<uint32_t>() : nullptr; sa.gshift = plan.gshift;
         SQE_TRY(launch_select_rescore(sa, s));
         // second pass for the queries whose certificate failed.  They are compacted into a dense batch on
         // the device (no host round trip): the collect scan then costs what a batch of that size costs.
@@ -490,6 +492,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
             a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
             a.dbg_counters = nullptr;
+            a.q_resid = nullptr; a.db_resid_max = nullptr;
             a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
             a.unc_count = unc_count;
             const int bounds[5] = {0, 64, 256, 512, 1 << 30};
@@ -519,7 +522,10 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         unsigned long long h[8];
         SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 64, hipMemcpyDeviceToHost, s));
         SQE_HIP(hipStreamSynchronize(s));
-        fprintf(stderr, "[sqe dbg] appends=%llu slow_path_entries=%llu compactions=%llu\n", h[0], h[1], h[2]);
+        int wall_khz = 0;
+        (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device);
+        fprintf(stderr, "[sqe dbg] appends=%llu slow_path_entries=%llu compactions=%llu block0_core_ticks=%llu wall_ticks=%llu core_mhz=%.0f\n",
+                h[0], h[1], h[2], h[4], h[5], h[5] ? (double)h[4] / (double)h[5] * wall_khz / 1e3 : 0.0);
     }
     c->search_calls++;
     c->last_scan_rows.store(n_rows);

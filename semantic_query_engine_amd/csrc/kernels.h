@@ -41,8 +41,17 @@ struct ScanPlan {
     int kp;               // candidates kept per (chunk, query)
     int ngroups;          // rows of the global-bound table per query slice (1: chunk c folds its maxima into column c % 64)
     int gshift;           // log2 group size of the global bound (64 >> gshift >= kp); -1 = off
+    int gshift_k;         // log2 group size of the k-row bound (64 >> gshift_k >= k), used with the 2 eps slack; -1 = off
 };
-ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count);
+// k = 0: no k-row bound (the caller has no error bound for the scan scores)
+ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count, int k = 0);
+
+// Upper bound of |bf16 scan score - fp32 cosine| for a query with bf16 residual norm dq over rows whose residual
+// norms are at most dx:  |<q_b, x_b> - <q, x>| <= ||q_b|| ||x - x_b|| + ||q - q_b|| ||x||, plus the difference of
+// the two fp32 accumulation orders.  ONE definition: the scan's k-row bound and the certificate must agree on it.
+__host__ __device__ inline float scan_eps(float dq, float dx) {
+    return (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + 2.0e-4f;
+}
 
 struct ScanArgs {
     const bf16_t* db;     // [round_up(n_rows, 256)] rows of K bf16 at `db_pitch` bytes, zero rows past n_rows
@@ -55,6 +64,9 @@ struct ScanArgs {
     int* cand_cnt;        // [n_chunks, b_pad]
     uint32_t* gmax;       // [b_pad, ngroups, GMAX_COLS], zeroed before the launch
     unsigned long long* dbg_counters;   // null unless SQE_DBG has bit 32
+    // k-row bound (plan.gshift_k >= 0): error-bound inputs, as SelectArgs; null = bound off
+    const float* q_resid;
+    const uint32_t* db_resid_max;
     // collect pass (launch_scan_collect): see ExactArgs
     const float* collect_thr;
     uint64_t* collect_keys;
@@ -87,6 +99,10 @@ struct SelectArgs {
     const uint32_t* db_resid_max;  // max over rows of || x_hat - bf16(x_hat) || (float bits)
     int* unc_count;                // number of uncertified queries
     float* collect_thr;            // [b_pad] per query: +inf if certified, else (k-th true cosine) - eps
+    // the scan's global-bound table as the scan left it and the plan's gshift (null / -1: the scan ran without
+    // that bound): rows the scan dropped below the kp-row bound are bounded by the table's final value
+    const uint32_t* gmax;
+    int gshift;
 };
 int launch_select_rescore(const SelectArgs& args, hipStream_t stream);
 

@@ -151,22 +151,9 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     constexpr bool collect = COLLECT;                    // second pass for uncertified queries
     f.collect_keys = collect ? p.collect_keys + (size_t)q0 * EXACT_CAP : nullptr;
     f.collect_cnt = collect ? p.collect_cnt + q0 : nullptr;
-    for (int i = tid; i < BN; i += THREADS) {
-        const bool live = (q0 + i) < batch;
-        float ts = live ? -INFINITY : INFINITY;
-        uint64_t tk = live ? 0ull : ~0ull;
-        if (collect && live) {
-            // fixed threshold: every row whose scan score is >= collect_thr is collected
-            ts = p.collect_thr[q0 + i];
-            const uint32_t o = f32_orderable(ts);
-            tk = ts == INFINITY ? ~0ull : ((uint64_t)o << 32) - 1ull;
-        }
-        f.thr_key[i] = tk;
-        f.thr_s[i] = ts;
-        f.cnt[i] = 0;
-        f.cmax[i] = 0u;
-    }
-    if (tid < 16) f.flags[tid] = 0;
+    float* slack = reinterpret_cast<float*>(smem + OFF_F + FL::OFF_SLACK);
+    f.slack = slack;
+    filter_init<BN>(p, f, slack, q0, batch, collect ? p.collect_thr : nullptr, tid);
 
     // Tile sequence: entry 0 = first tile in BOOT mode, entries 1..nt-1 the other tiles, entry
     // nt = the first tile again, normally.  (nt == 0: nothing.)
@@ -213,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         // The fetch is younger than the DMA pieces of its own K step, so the counted wait that ends that
         // step leaves it in flight; the wait of the NEXT step retires it (NST = 2 drains everything every step).
         if (refresh_pending >= 0 && ++refresh_age >= (NST == 2 ? 1 : 2)) {
-            if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, lane);
+            if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, p.gshift_k, lane);
             refresh_pending = -1;
         }
         // prefetch stage s + NST - 1 (queries: s + NSTB - 1) into the buffer stage s - 1 used (its readers
@@ -226,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
             // Bound refresh schedule: entry 1 fetches every slice back to back from K step KS/4 on
             // (after every chunk has published its boot maxima); later one slice per tile.
             const bool want = entry == 1 ? (ks >= KS / 4 && refresh_ctr < NSLICE) : (entry > 1 && ks == 0);
-            if (want && p.gshift >= 0 && !collect && refresh_pending < 0) {
+            if (want && (p.gshift >= 0 || p.gshift_k >= 0) && !collect && refresh_pending < 0) {
                 refresh_age = 0;
                 refresh_pending = refresh_ctr % NSLICE;
                 ++refresh_ctr;
@@ -333,6 +320,8 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     // compaction buys, and a tile can add SCAN_BM entries on top before the next check
     k.trig = std::min(CAND_CAP - SCAN_BM, std::max(2 * plan.kp, 128));
     k.ngroups = plan.ngroups; k.gshift = plan.gshift;
+    k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max;
+    k.gshift_k = (a.q_resid && a.db_resid_max) ? plan.gshift_k : -1;
     {
         static const int krot = [] { const char* e = knob_env("SQE_KROT"); return e ? atoi(e) : 0; }();
         static const int dbg = [] { const char* e = knob_env("SQE_DBG"); return e ? atoi(e) : 0; }();
@@ -345,7 +334,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     return k;
 }
 
-ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
+ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count, int k) {
     ScanPlan p;
     p.bn = B > 128 ? 256 : B > 64 ? 128 : 64;          // 128: HBM-bound like 64, half the padding of a 256 block
     p.qblocks = (B + p.bn - 1) / p.bn;
@@ -363,7 +352,10 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count) {
     p.ngroups = 1;
     // global bound: 64 >> gshift groups, each contributing one distinct row, must be >= kp
     p.gshift = kp <= 16 ? 2 : kp <= 32 ? 1 : kp <= 64 ? 0 : -1;
-    if (p.n_chunks < GMAX_COLS) p.gshift = -1;          // a column without a chunk: no cross-chunk bound
+    // k-row bound (scan_common.h: refresh_apply): fewer, larger groups; pointless where it names the same groups
+    p.gshift_k = k < 1 ? -1 : k <= 16 ? 2 : k <= 32 ? 1 : k <= 64 ? 0 : -1;
+    if (p.gshift_k <= p.gshift) p.gshift_k = -1;
+    if (p.n_chunks < GMAX_COLS) p.gshift = p.gshift_k = -1;   // a column without a chunk: no cross-chunk bound
     return p;
 }
 

@@ -52,6 +52,9 @@ struct ScanKernelArgs {
     int trig;            // compaction trigger (kp <= trig <= CAND_CAP - SCAN_BM)
     int ngroups;         // table rows per query slice (1: chunk c folds its maxima into column c % 64)
     int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
+    int gshift_k;        // log2 of the group size of the k-row bound (threshold = bound - slack); < 0: off
+    const float* q_resid;            // [B] error-bound inputs of the k-row bound (kernels.h: scan_eps)
+    const uint32_t* db_resid_max;
     int krot;            // workgroup w walks K rotated by w * krot steps
     int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter,
                          //   8 = no global-bound refresh, 16 = filter fast path only
@@ -75,7 +78,8 @@ struct FilterLds {
     static constexpr int OFF_THR_S = OFF_THR_KEY + BN * 8;      // float  [BN]
     static constexpr int OFF_CNT = OFF_THR_S + BN * 4;          // int    [BN]
     static constexpr int OFF_CMAX = OFF_CNT + BN * 4;           // uint32 [BN] chunk max (orderable)
-    static constexpr int OFF_FLAGS = OFF_CMAX + BN * 4;         // int    [16]
+    static constexpr int OFF_SLACK = OFF_CMAX + BN * 4;         // float  [BN] 2 eps + margin of the k-row bound
+    static constexpr int OFF_FLAGS = OFF_SLACK + BN * 4;        // int    [16]
     static constexpr int OFF_GSTAGE = OFF_FLAGS + 64;           // uint32 [GSLICE_Q][GMAX_COLS]
     static constexpr int BYTES = OFF_GSTAGE + GSTAGE_BYTES;
 };
@@ -112,6 +116,7 @@ struct Filter {
     float* thr_s;
     int* cnt;
     uint32_t* cmax;
+    const float* slack;    // per query: what the k-row bound is lowered by
     int* flags;            // [8] per owner wave: an owned list reached the compaction trigger
     int64_t n_rows;
     int q_live;            // live queries in this block
@@ -336,30 +341,65 @@ __device__ __forceinline__ void refresh_issue(const uint32_t* gmax_block_group, 
 }
 
 // After the fetch has landed: ONE wave folds the slice, lane = query.  Walks the 64 columns
-// (conflict-free ds_read_b32, no cross-lane traffic): max inside groups of 2^gshift columns,
-// min over the groups.
-__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift, int lane) {
+// (conflict-free ds_read_b32, no cross-lane traffic) four at a time and keeps, for group sizes 1, 2 and 4, the
+// minimum over the groups of the maximum inside a group.  Two bounds come out of it:
+//   * the kp-row bound (group size 2^gshift, 64 >> gshift >= kp groups): a score kp distinct rows reach;
+//   * the k-row bound (group size 2^gshift_k, 64 >> gshift_k >= k groups) LOWERED BY 2 eps: L is a scan score k
+//     distinct rows reach, so their true cosines are >= L - eps, and a row whose scan score is below L - 2 eps
+//     has a true cosine below L - eps: it cannot be in the exact top-k.  Rows dropped under this bound need no
+//     certificate; with k = 10 of kp = 64 it sits well above the kp-row bound (fewer, larger groups beat the
+//     slack of ~0.16 sigma on 1024-d data), which is what makes tiles without any survivor the common case.
+// The query's threshold becomes the larger of the two (and of what it was).
+__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift, int gshift_k, int lane) {
     const uint32_t* st = reinterpret_cast<const uint32_t*>(gstage) + lane;
-    uint32_t bound = 0xFFFFFFFFu;
-    if (gshift == 0) {
-#pragma unroll 16
-        for (int c = 0; c < GMAX_COLS; ++c) bound = min(bound, st[c * 64]);
-    } else if (gshift == 1) {
-#pragma unroll 8
-        for (int c = 0; c < GMAX_COLS; c += 2) bound = min(bound, max(st[c * 64], st[(c + 1) * 64]));
-    } else {
+    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, b4 = 0xFFFFFFFFu;
 #pragma unroll 4
-        for (int c = 0; c < GMAX_COLS; c += 4)
-            bound = min(bound, max(max(st[c * 64], st[(c + 1) * 64]), max(st[(c + 2) * 64], st[(c + 3) * 64])));
+    for (int c = 0; c < GMAX_COLS; c += 4) {
+        const uint32_t v0 = st[c * 64], v1 = st[(c + 1) * 64], v2 = st[(c + 2) * 64], v3 = st[(c + 3) * 64];
+        const uint32_t p0 = max(v0, v1), p1 = max(v2, v3);
+        b1 = min(b1, min(min(v0, v1), min(v2, v3)));
+        b2 = min(b2, min(p0, p1));
+        b4 = min(b4, max(p0, p1));
     }
+    const uint32_t bound = gshift == 0 ? b1 : gshift == 1 ? b2 : gshift == 2 ? b4 : 0u;
+    const uint32_t lk = gshift_k == 0 ? b1 : gshift_k == 1 ? b2 : gshift_k == 2 ? b4 : 0u;
     const int q = sl * GSLICE_Q + lane;
-    if (bound != 0u && q < f.q_live) {
-        const uint64_t gk = (uint64_t)bound << 32;
-        if (gk > f.thr_key[q]) {
-            f.thr_key[q] = gk;
-            f.thr_s[q] = f32_from_orderable(bound);
+    if (q < f.q_live) {
+        uint32_t best = bound;                                   // 0 = some column not published yet / bound off
+        if (lk != 0u) best = max(best, f32_orderable(f32_from_orderable(lk) - f.slack[q]));
+        if (best != 0u) {
+            const uint64_t gk = (uint64_t)best << 32;
+            if (gk > f.thr_key[q]) {
+                f.thr_key[q] = gk;
+                f.thr_s[q] = f32_from_orderable(best);
+            }
         }
     }
+}
+
+// Filter state of a query block at kernel start (every thread of the workgroup; `collect_thr` non-null: COLLECT
+// mode, fixed thresholds).  The slack of the k-row bound is 2 eps plus a margin for the rounding of L - slack.
+template <int BN>
+__device__ __forceinline__ void filter_init(const ScanKernelArgs& p, const Filter& f, float* slack, int q0, int batch,
+                                            const float* collect_thr, int tid) {
+    const float dx = (p.gshift_k >= 0 && p.db_resid_max) ? __uint_as_float(*p.db_resid_max) : 0.f;
+    for (int i = tid; i < BN; i += SCAN_THREADS) {
+        const bool live = (q0 + i) < batch;
+        float ts = live ? -INFINITY : INFINITY;
+        uint64_t tk = live ? 0ull : ~0ull;
+        if (collect_thr && live) {
+            // fixed threshold: every row whose scan score is >= collect_thr is collected
+            ts = collect_thr[q0 + i];
+            const uint32_t o = f32_orderable(ts);
+            tk = ts == INFINITY ? ~0ull : ((uint64_t)o << 32) - 1ull;
+        }
+        f.thr_key[i] = tk;
+        f.thr_s[i] = ts;
+        f.cnt[i] = 0;
+        f.cmax[i] = 0u;
+        slack[i] = (live && p.gshift_k >= 0 && p.q_resid) ? 2.0f * scan_eps(p.q_resid[q0 + i], dx) * 1.000001f + 1.0e-6f : INFINITY;
+    }
+    if (tid < 16) f.flags[tid] = 0;
 }
 
 }  // namespace sqe

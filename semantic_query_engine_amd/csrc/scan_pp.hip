@@ -89,12 +89,13 @@ struct PP {
     int wave, wm, wn;
     int tile_begin, nt, HS, J;
     long long tile_bytes;
-    int kp, trig, gshift, refresh_every;
+    int kp, trig, gshift, gshift_k, refresh_every;
     Cursor rd;                             // half-step the next MEM phase reads
     Cursor dm;                             // half-step the next MEM phase fetches (rd + 3)
     int refresh_pending, refresh_ctr, refresh_j;
     int lean_until;                        // MEM phases of half-steps < lean_until take the lean form
     bool no_mma, no_dma, no_filter;
+    bool bound_on;                         // some cross-chunk bound is in use (kp-row and / or k-row)
 
     __device__ __forceinline__ void advance(Cursor& c) const {
         if (++c.h == HS) {
@@ -219,13 +220,13 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     // ---- global bound: fold a slice fetched >= 3 half-steps ago (every wave's pieces have been
     // retired by its counted waits and a barrier), then maybe fetch the next one
     if (P.refresh_pending >= 0 && j >= P.refresh_j + 3) {
-        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, fresh_lane());
+        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.gshift_k, fresh_lane());
         P.refresh_pending = -1;
     }
     // Schedule: entry 1 fetches all slices back to back from a quarter of the tile on
     // (when every chunk has published its boot maxima), then every slice once per tile while the
     // bound still moves fast, one slice per tile later.  At least 4 half-steps between fetches.
-    if (P.gshift >= 0 && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && j >= P.refresh_j + 4) {
+    if (P.bound_on && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && j >= P.refresh_j + 4) {
         const bool want = P.rd.e == 1 ? (P.rd.h >= P.HS / 4 && P.refresh_ctr < NSLICEP)
                                       : (P.rd.e <= 32 ? (P.rd.h % P.refresh_every) == 0 : P.rd.h == 0);
         if (want) {
@@ -257,7 +258,7 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     // ---- first half-step that needs this (general) form again; until then mem_lean runs
     int next = j + 1;
     if (P.refresh_pending < 0 && P.rd.e >= 2) {
-        if (P.gshift < 0 || P.no_filter || P.rd.e > 32) next = P.J;          // next fetch: a FILTER phase
+        if (!P.bound_on || P.no_filter || P.rd.e > 32) next = P.J;          // next fetch: a FILTER phase
         else next = j + (P.refresh_every - (P.rd.h % P.refresh_every));
     }
     P.lean_until = P.no_dma ? 0 : min(next, P.J - 3);
@@ -284,6 +285,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#ifdef SQE_FILTER_COUNTERS
+    const long long clk0 = clock64(), wall0 = wall_clock64();     // core-clock and constant-rate ticks (SQE_DBG bit 32)
+#endif
     PP P;
     P.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = P.wave >> 2;           // waves w and w + 4 share a SIMD
@@ -308,10 +312,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     P.J = n_entries * P.HS;
     const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
     P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
-    P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift;
+    P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift; P.gshift_k = p.gshift_k;
     P.refresh_every = P.HS >= NSLICEP ? P.HS / NSLICEP : 1;
     P.no_mma = (SQE_DBG_BITS(p) & 1) != 0; P.no_dma = (SQE_DBG_BITS(p) & 2) != 0; P.no_filter = (SQE_DBG_BITS(p) & 4) != 0;
-    if (SQE_DBG_BITS(p) & 8) P.gshift = -1;
+    if (SQE_DBG_BITS(p) & 8) P.gshift = P.gshift_k = -1;
+    if (SQE_DBG_BITS(p) & 64) P.gshift_k = -1;          // kp-row bound only (the r01 filter)
+    P.bound_on = P.gshift >= 0 || P.gshift_k >= 0;
 
     Filter f;
     f.cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
@@ -329,14 +335,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     f.dbg_no_slow = (SQE_DBG_BITS(p) & 16) != 0;
     f.dbg_counters = (SQE_DBG_BITS(p) & 32) ? p.dbg_counters : nullptr;
     f.collect_keys = nullptr; f.collect_cnt = nullptr;
-    for (int i = tid; i < BNP; i += SCAN_THREADS) {
-        const bool live = (q0 + i) < p.B;
-        f.thr_key[i] = live ? 0ull : ~0ull;
-        f.thr_s[i] = live ? -INFINITY : INFINITY;
-        f.cnt[i] = 0;
-        f.cmax[i] = 0u;
-    }
-    if (tid < 16) f.flags[tid] = 0;
+    float* slack = reinterpret_cast<float*>(smem + OFF_F + FLP::OFF_SLACK);
+    f.slack = slack;
+    filter_init<BNP>(p, f, slack, q0, p.B, nullptr, tid);
 
     // ---- per-lane DMA source offsets.  Piece t covers LDS lines 8t .. 8t+7; lane l writes chunk
     // position l & 7 of line 8t + (l >> 3), which holds logical chunk c = pos ^ ((line >> 1) & 7):
@@ -474,6 +475,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     __syncthreads();
     for (int i = tid; i < BNP; i += SCAN_THREADS)
         p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
+#ifdef SQE_FILTER_COUNTERS
+    if (f.dbg_counters && blockIdx.x == 0 && tid == 0) {
+        f.dbg_counters[4] = (unsigned long long)(clock64() - clk0);
+        f.dbg_counters[5] = (unsigned long long)(wall_clock64() - wall0);
+    }
+#endif
 }
 
 }  // namespace

@@ -29,6 +29,8 @@ struct SelectKernelArgs {
     const uint32_t* db_resid_max;
     int* unc_count;
     float* collect_thr;
+    const uint32_t* gmax;
+    int gshift;
 };
 
 // MSB-first byte-wise radix select of the `kth` largest of n keys.  `get(e)` returns key e (0 = no key).
@@ -173,19 +175,31 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
         cos_out[i] = -INFINITY;
         id_out[i] = -1;
     }
-    // ---- exactness certificate.  Rows that are not candidates have a scan key below T, i.e. a bf16
-    // scan score <= score(T); a scan score differs from the true fp32 cosine by at most
-    //   |<q_b, x_b> - <q, x>| <= ||q_b|| * ||x - x_b|| + ||q - q_b|| * ||x||  (+ fp32 accumulation),
-    // so no unseen row can reach score(T) + eps.  T == 0: every row of the index is a candidate.
+    // ---- exactness certificate.  A row that is not a candidate was
+    //   (a) dropped under the scan's k-row bound: excluded rigorously there (scan_common.h: refresh_apply);
+    //   (b) dropped under the kp-row bound: its scan score is below that bound's FINAL value, which the table
+    //       the scan left behind still gives (columns and bound only rise);
+    //   (c) cut from a chunk's list or from the union here: its key is below T, the kp-th best key of the union
+    //       (T == 0: the union has fewer than kp keys and nothing was cut).
+    // A scan score differs from the true fp32 cosine by at most eps (kernels.h: scan_eps), so no row of (b) or
+    // (c) can reach max(score(T), bound) + eps.
     if (p.unc_count) {
+        float gfin = -INFINITY;
+        if (p.gmax && p.gshift >= 0 && wave == 0) {
+            uint32_t v = p.gmax[((size_t)(q >> 6) * GMAX_COLS + lane) * 64 + (q & 63)];      // column `lane`
+            if (p.gshift >= 1) v = max(v, (uint32_t)__shfl_xor((int)v, 1, 64));
+            if (p.gshift >= 2) v = max(v, (uint32_t)__shfl_xor((int)v, 2, 64));
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+            if (v != 0u) gfin = f32_from_orderable(v);
+        }
         __syncthreads();
         if (tid == 0) {
             float thr = INFINITY;                    // certified: nothing to collect
-            if (T != 0ull) {
-                const float dq = p.q_resid[q];
-                const float dx = __uint_as_float(*p.db_resid_max);
-                const float eps = (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + 2.0e-4f;
-                const bool certified = m >= p.k && kth_score > key_score(T) + eps;
+            const float unseen = fmaxf(T != 0ull ? key_score(T) : -INFINITY, gfin);
+            if (unseen > -INFINITY) {
+                const float eps = scan_eps(p.q_resid[q], __uint_as_float(*p.db_resid_max));
+                const bool certified = m >= p.k && kth_score > unseen + eps;
                 if (!certified) {
                     atomicAdd(p.unc_count, 1);
                     thr = (m >= p.k ? kth_score : -1.0f) - eps;
@@ -254,6 +268,7 @@ int launch_select_rescore(const SelectArgs& a, hipStream_t stream) {
     k.master = a.master; k.qn = a.qn; k.K = a.K; k.B = a.B; k.k = a.k;
     k.cos_out = a.cos_out; k.id_out = a.id_out; k.id_base = a.id_base;
     k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max; k.unc_count = a.unc_count; k.collect_thr = a.collect_thr;
+    k.gmax = a.gmax; k.gshift = a.gmax ? a.gshift : -1;
     if ((int64_t)a.n_chunks * a.kp > 4096) {              // few query blocks, many chunks: B <= 256
         constexpr int LDS = 16384 * 8;
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(select_rescore_kernel<1024, 16384>), LDS));

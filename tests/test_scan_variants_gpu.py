@@ -61,3 +61,12 @@ def test_128_query_tile_ring_depths(ring, knobs_env):
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "batch": 100}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
+
+
+def test_kp_row_bound_alone(knobs_env):
+    """SQE_DBG=64 switches the k-row bound off (thresholds from the kp-row bound and the per-chunk lists only,
+    the r01 filter): a timing switch that must not change any answer."""
+    env = dict(knobs_env, SQE_DBG="64")
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "batch": 300}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True

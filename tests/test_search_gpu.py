@@ -265,3 +265,29 @@ def test_random_session_against_oracle(ctx):
         ref_cos, ref_ids = R.knn_search(x, q, k)
         assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
     assert len(idx) == x.shape[0]
+
+
+@pytest.mark.parametrize("b,k", [(200, 16), (600, 10), (64, 16)])
+def test_k_row_bound_keeps_rows_inside_the_error_band(ctx, b, k):
+    """The scan drops rows below (a score k distinct rows reach) - 2 eps without a certificate (scan_common.h:
+    refresh_apply).  Per query, 40 planted rows whose true cosines differ by 1e-5 -- far below the bf16 noise of
+    the scan scores (~1e-4) -- so the bf16 order of the true top-k is scrambled and several of them score BELOW
+    the k-row bound itself; only the 2 eps slack keeps them.  Enough rows for the cross-chunk bound to be active
+    (>= 64 chunks).  Ids and order must equal the float64 oracle."""
+    rng = np.random.default_rng(900 + b + k)
+    d, n, planted = 256, 40000, 40
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    qn = R.normalize_rows(q).astype(np.float64)
+    rows = rng.permutation(n)[:b * planted].reshape(b, planted)
+    for i in range(b):
+        noise = rng.standard_normal((planted, d))
+        noise -= (noise @ qn[i])[:, None] * qn[i][None, :]
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        c = 0.6 - 1e-5 * rng.permutation(planted)
+        x[rows[i]] = (c[:, None] * qn[i][None, :] + np.sqrt(1 - c * c)[:, None] * noise).astype(np.float32)
+    idx = _index(ctx, x)
+    cos, ids = idx.search(q, k)
+    ref_cos, ref_ids = R.knn_search(x, q, k)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    assert all(set(ids[i].tolist()) <= set(rows[i].tolist()) for i in range(b))

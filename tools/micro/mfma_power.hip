@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // 8 x 4 fragments of 16x16x32 per wave and trip: 32 MFMAs, 32 * 16*16*32*2 flop = 524288 flop
 __global__ __launch_bounds__(512) void k16(const bf16x8* __restrict__ src, float* __restrict__ out, int trips) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     bf16x8 a[8], b[4];
     const int lane = threadIdx.x & 63;
     for (int i = 0; i < 8; ++i) a[i] = src[(i * 64 + lane) & 4095];
@@ -32,10 +33,15 @@ __global__ __launch_bounds__(512) void k16(const bf16x8* __restrict__ src, float
     for (int i = 0; i < 8; ++i)
         for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 12345.678f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // core-clock and 100 MHz wall-clock ticks of this wave
+        reinterpret_cast<long long*>(out)[1] = clock64() - c0;
+        reinterpret_cast<long long*>(out)[2] = wall_clock64() - w0;
+    }
 }
 
 // 4 x 2 fragments of 32x32x16 per wave and trip, two K halves: 16 MFMAs of 32*32*16*2 flop = 524288 flop
 __global__ __launch_bounds__(512) void k32(const bf16x8* __restrict__ src, float* __restrict__ out, int trips) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     bf16x8 a[8], b[4];
     const int lane = threadIdx.x & 63;
     for (int i = 0; i < 8; ++i) a[i] = src[(i * 64 + lane) & 4095];
@@ -54,6 +60,10 @@ __global__ __launch_bounds__(512) void k32(const bf16x8* __restrict__ src, float
         for (int j = 0; j < 2; ++j)
             for (int e = 0; e < 16; ++e) s += acc[i][j][e];
     if (s == 12345.678f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // core-clock and 100 MHz wall-clock ticks of this wave
+        reinterpret_cast<long long*>(out)[1] = clock64() - c0;
+        reinterpret_cast<long long*>(out)[2] = wall_clock64() - w0;
+    }
 }
 
 static uint16_t bf16_of(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
@@ -65,7 +75,7 @@ int main(int argc, char** argv) {
     const int cus = prop.multiProcessorCount;
     std::vector<uint16_t> h(4096 * 8);
     bf16x8* src; float* out;
-    CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&out, 4));
+    CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&out, 64));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const char* data_names[3] = {"zeros", "gauss(0,1/32)", "gauss, 2 waves/SIMD"};
     for (int shape = 0; shape < 2; ++shape)
@@ -89,8 +99,14 @@ int main(int argc, char** argv) {
                 last = flop / (ms * 1e-3) / 1e12;
                 if (last > best) best = last;
             }
-            printf("{\"shape\": \"%s\", \"data\": \"%s\", \"cus\": %d, \"waves_per_simd\": %d, \"tflops_last\": %.1f, \"tflops_best\": %.1f}\n",
-                   shape ? "32x32x16" : "16x16x32", data_names[data], cus, threads / 256, last, best);
+            long long ticks[3];
+            CK(hipMemcpy(ticks, out, 24, hipMemcpyDeviceToHost));
+            int wall_khz = 0;
+            CK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
+            printf("{\"shape\": \"%s\", \"data\": \"%s\", \"cus\": %d, \"waves_per_simd\": %d, \"tflops_last\": %.1f, \"tflops_best\": %.1f, "
+                   "\"clock64_ticks\": %lld, \"wall_ticks\": %lld, \"wall_khz\": %d, \"clock64_mhz\": %.0f}\n",
+                   shape ? "32x32x16" : "16x16x32", data_names[data], cus, threads / 256, last, best, ticks[1], ticks[2], wall_khz,
+                   ticks[2] ? (double)ticks[1] / ticks[2] * wall_khz / 1e3 : 0.0);
             fflush(stdout);
         }
     return 0;
