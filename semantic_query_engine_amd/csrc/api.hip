@@ -452,8 +452,8 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         {
             static const bool want = [] { const char* e = knob_env("SQE_DBG"); return e && (atoi(e) & 32); }();   // knobs build only
             if (want) {
-                SQE_TRY(idx->dbg.ensure(64));
-                SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 64, s));
+                SQE_TRY(idx->dbg.ensure(4096));
+                SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 4096, s));
                 a.dbg_counters = idx->dbg.as<unsigned long long>();
             }
         }
@@ -519,13 +519,39 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         c->unc_valid.store(true);
     }
     if (idx->dbg.p) {
-        unsigned long long h[8];
-        SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 64, hipMemcpyDeviceToHost, s));
+        unsigned long long h[512];
+        SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 4096, hipMemcpyDeviceToHost, s));
         SQE_HIP(hipStreamSynchronize(s));
         int wall_khz = 0;
         (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device);
         fprintf(stderr, "[sqe dbg] appends=%llu slow_path_entries=%llu compactions=%llu block0_core_ticks=%llu wall_ticks=%llu core_mhz=%.0f\n",
                 h[0], h[1], h[2], h[4], h[5], h[5] ? (double)h[4] / (double)h[5] * wall_khz / 1e3 : 0.0);
+        // ping-pong scan, counters build: core cycles per steady-state phase, per wave of workgroups 0 and 100
+        for (int blk = 0; blk < 2; ++blk)
+            for (int w = 0; w < 8; ++w) {
+                const unsigned long long* o = h + 8 + blk * 64 + w * 8;
+                if (!o[0]) continue;
+                const double n = (double)o[0];
+                fprintf(stderr, "[sqe dbg] wg %d wave %d: phases=%llu  cmp %.0f  barrier after cmp %.0f | mem: dma issue %.0f  lds reads issue %.0f  waitcnt %.0f  barrier after mem %.0f\n",
+                        blk ? 100 : 0, w, o[0], o[1] / n, o[2] / n, o[3] / n, o[4] / n, o[5] / n, o[6] / n);
+            }
+        for (int blk = 0; blk < 2; ++blk) {
+            const unsigned long long* o = h + 8 + 128 + blk * 16;
+            if (!o[11]) continue;
+            const double t = (double)o[11];
+            fprintf(stderr, "[sqe dbg] wg %d wave 0, cycles per tile: first cmp %.0f + barrier %.0f, mem %.0f + barrier %.0f | last cmp (fast-path test) %.0f + barrier %.0f, "
+                            "mem of next tile %.0f + barrier %.0f, tile_end %.0f | %.2f general middle half-steps per tile at %.0f cycles each\n",
+                    blk ? 100 : 0, o[0] / t, o[1] / t, o[2] / t, o[3] / t, o[4] / t, o[5] / t, o[6] / t, o[7] / t, o[8] / t, o[10] / t,
+                    o[10] ? (double)o[9] / (double)o[10] : 0.0);
+        }
+        for (int blk = 0; blk < 2; ++blk)
+            for (int w = 0; w < 8; ++w) {
+                const unsigned long long* o = h + 8 + 160 + blk * 48 + w * 6;
+                if (!o[5]) continue;
+                const double n = (double)o[5];
+                fprintf(stderr, "[sqe dbg] wg %d wave %d tile_end x %llu: mark read %.0f, own slow path %.0f (flagged in %.0f %%), barrier %.0f, entry_sync %.0f\n",
+                        blk ? 100 : 0, w, o[5], o[0] / n, o[1] / n, 100.0 * o[4] / n, o[2] / n, o[3] / n);
+            }
     }
     c->search_calls++;
     c->last_scan_rows.store(n_rows);

@@ -25,6 +25,8 @@
 //     pipelined loops: a VGPR load would make hipcc drain the DMA queue).
 #pragma once
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace sqe {
@@ -255,68 +257,140 @@ __device__ __forceinline__ void publish_cmax(const Filter& f, int first_q, int p
     }
 }
 
+// OR over the 64 lanes of a wave (all lanes active): four DPP row shifts leave the OR of a 16-lane row in its last
+// lane, four v_readlane collect the rows.  Uniform result.
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1, zero fill
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15) | (unsigned)__builtin_amdgcn_readlane((int)v, 31) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, 47) | (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// accumulator number t (fragment t >> 2, element t & 3) of column group J, t uniform: a switch, i.e. a short
+// compare tree in front of FM * 4 one-instruction cases -- registers cannot be indexed by a run-time value
+template <int FM, int FN, int J>
+__device__ __forceinline__ float pick_acc(const f32x4 (&acc)[FM][FN], int t) {
+    static_assert(FM == 2 || FM == 4 || FM == 8, "fragment rows per wave");
+    float v = 0.f;
+    // every case is an opaque one-instruction copy: without the asm hipcc turns the switch into an array in scratch
+    // memory (FM * 4 stores + one indexed load per call -- vector memory traffic in the middle of the DMA ring)
+#define SQE_PICK(n)                                                          \
+    case n:                                                                  \
+        if constexpr ((n) < FM * 4) asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(acc[((n) >> 2) % FM][J][(n) & 3])); \
+        break;
+#define SQE_PICK4(n) SQE_PICK(n) SQE_PICK((n) + 1) SQE_PICK((n) + 2) SQE_PICK((n) + 3)
+    switch (t) {
+        SQE_PICK4(0) SQE_PICK4(4) SQE_PICK4(8) SQE_PICK4(12) SQE_PICK4(16) SQE_PICK4(20) SQE_PICK4(24) SQE_PICK4(28)
+        default: break;
+    }
+#undef SQE_PICK4
+#undef SQE_PICK
+    return v;
+}
+
+// Slow path of one column group J of a finished tile.  Code size is what matters here: the path runs a few times per
+// tile in a wave or two, from instructions that are cold by then, so the r01 form -- the whole append sequence
+// unrolled at each of the FM * 4 accumulators of each group, ~180 KB of kernel -- spent most of its time fetching
+// instructions.  Now: (1) one pass of v_cmp + v_addc shifts, per lane, a bit per accumulator at or above the query's
+// threshold into a mask; (2) ONE LDS atomic per lane reserves its list slots; (3) a scalar loop walks the bits set
+// in ANY lane, fetches that accumulator (pick_acc) and runs one copy of the append sequence -- no LDS round trip
+// inside -- for the lanes that have the bit.
+template <int FM, int FN, int J, bool COLLECT>
+__device__ __forceinline__ bool filter_group(const f32x4 (&acc)[FM][FN], const Filter& f, int64_t row_base, bool partial,
+                                             int qcol, float thr, uint32_t cmax0) {
+    unsigned m = 0;
+    // element t = i * 4 + r ends up in bit t: every step shifts the mask left and adds the compare bit, last element first
+#pragma unroll
+    for (int t = FM * 4 - 1; t >= 0; --t)
+        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(acc[t >> 2][J][t & 3]), "v"(thr) : "vcc");
+    if (partial) {                                  // last tile of the index: rows past the end are not rows
+        const int left = (int)min((int64_t)SCAN_BM, max((int64_t)0, f.n_rows - row_base));   // valid rows from row_base on
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int n = min(4, max(0, left - i * 16));          // valid elements of fragment i
+            valid |= ((1u << n) - 1u) << (i * 4);
+        }
+        m &= valid;
+    }
+    if (qcol >= f.q_live) m = 0;
+    if (f.dbg_no_slow) m = 0;
+    unsigned todo = wave_or_u32(m);
+    if (todo == 0) return false;                    // the threshold has risen since the fast test
+    SQE_COUNT(f, 1, (threadIdx.x & 63) == 0);
+    // Keys are appended on score alone (>= threshold): at equal score a key below the threshold KEY (higher row id)
+    // may come along, and the next compaction drops it again.
+    const int mine = __popc(m);
+    int slot = 0;
+    if (mine) slot = atomicAdd(COLLECT ? &f.collect_cnt[qcol] : &f.cnt[qcol], mine);
+    uint32_t best = 0;
+    if constexpr (!COLLECT) {
+        if (mine && slot + mine >= f.trig) f.flags[qcol / f.per_wave] = 1;
+    }
+    uint64_t* list = COLLECT ? f.collect_keys + (size_t)qcol * EXACT_CAP : f.cand_base + (size_t)qcol * CAND_CAP;
+    while (todo) {
+        const int t = __builtin_ctz(todo);          // uniform
+        todo &= todo - 1;
+        const float sc = pick_acc<FM, FN, J>(acc, t);
+        if (m & (1u << t)) {
+            const int64_t row = row_base + (t >> 2) * 16 + (t & 3);
+            const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
+            if (!COLLECT || slot < EXACT_CAP) list[slot] = key;
+            ++slot;
+            SQE_COUNT(f, 0, true);
+            best = max(best, (uint32_t)(key >> 32));
+        }
+    }
+    if constexpr (!COLLECT) {
+        // the chunk maximum only rises, so the stale cmax0 only publishes a maximum that is already known
+        if (best > cmax0) {
+            atomicMax(&f.cmax[qcol], best);          // no return value: fire and forget
+            publish_max_u32(f.gmax_mine + (size_t)(qcol >> 6) * f.gstride + (qcol & 63), best);
+        }
+    }
+    return !COLLECT && mine != 0;
+}
+
 // Normal mode.  Returns true when this wave stored candidates (the caller drains its stores
 // before the next barrier so other waves can read the lists).
 // `cols`: wave-uniform mask of the column groups to look at (the ping-pong kernel finds the groups that hold a
-// survivor under its MFMAs -- pp_colmax -- and only those come here); all groups by default.
+// survivor under its MFMAs and only those come here); all groups by default, behind a max test of their own.
 template <int FM, int FN, bool COLLECT = false>
 __device__ __forceinline__ bool filter_tile(const f32x4 (&acc)[FM][FN], const Filter& f, int64_t tile_row0,
                                             int row0, int col0, int lane, unsigned cols = ~0u) {
+    static_assert(FN == 4, "four column groups per wave");
     bool stored = false;
     const int64_t row_base = tile_row0 + row0 + (lane >> 4) * 4;
+    const bool partial = tile_row0 + SCAN_BM > f.n_rows;
+    const bool pretested = cols != ~0u;
+    // thresholds and chunk maxima of the four groups: one LDS round trip for all of them
+    float thr[FN];
+    uint32_t cmax0[FN];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        if (!(cols & (1u << j))) continue;
-        const int qcol = col0 + j * 16 + (lane & 15);
-        const float thr = f.thr_s[qcol];
-        float fmx[FM];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            fmx[i] = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
-            mx = fmaxf(mx, fmx[i]);
-        }
-        if (__any(mx >= thr) && !f.dbg_no_slow) {    // rare: some lane of this column group has a survivor
-            SQE_COUNT(f, 1, lane == 0);
-            // One LDS round trip per appended key (the slot counter): the query's threshold key and the chunk
-            // maximum are read once up here.  Both only rise, so a stale value only admits a key the next
-            // compaction drops again, or publishes a maximum that is already known.
-            const uint64_t tkey = f.thr_key[qcol];
-            const uint32_t cmax0 = f.cmax[qcol];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                if (__any(fmx[i] >= thr)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sc = acc[i][j][r];
-                        if (sc >= thr) {
-                            const int64_t row = row_base + i * 16 + r;
-                            if (row < f.n_rows && qcol < f.q_live) {
-                                const uint64_t key = make_key(sc + 0.0f, (uint32_t)row);
-                                if (key > tkey) {
-                                    if constexpr (COLLECT) {
-                                        const int gslot = atomicAdd(&f.collect_cnt[qcol], 1);
-                                        if (gslot < EXACT_CAP) f.collect_keys[(size_t)qcol * EXACT_CAP + gslot] = key;
-                                        continue;
-                                    }
-                                    const int slot = atomicAdd(&f.cnt[qcol], 1);
-                                    SQE_COUNT(f, 0, true);
-                                    f.cand_base[(size_t)qcol * CAND_CAP + slot] = key;
-                                    if (slot + 1 >= f.trig) f.flags[qcol / f.per_wave] = 1;
-                                    const uint32_t o = (uint32_t)(key >> 32);
-                                    if (o > cmax0) {
-                                        atomicMax(&f.cmax[qcol], o);      // no return value: fire and forget
-                                        publish_max_u32(f.gmax_mine + (size_t)(qcol >> 6) * f.gstride + (qcol & 63), o);
-                                    }
-                                    stored = true;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
+    for (int jj = 0; jj < FN; ++jj) {
+        const int qcol = col0 + jj * 16 + (lane & 15);
+        thr[jj] = f.thr_s[qcol];
+        cmax0[jj] = COLLECT ? 0u : f.cmax[qcol];
     }
+    auto group = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if (!(cols & (1u << J))) return;
+        const int qcol = col0 + J * 16 + (lane & 15);
+        if (!pretested) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[i][J][0], acc[i][J][1]), fmaxf(acc[i][J][2], acc[i][J][3])));
+            if (!__any(mx >= thr[J])) return;
+        }
+        stored |= filter_group<FM, FN, J, COLLECT>(acc, f, row_base, partial, qcol, thr[J], cmax0[J]);
+    };
+    group(std::integral_constant<int, 0>{});
+    group(std::integral_constant<int, 1>{});
+    group(std::integral_constant<int, 2>{});
+    group(std::integral_constant<int, 3>{});
     return __any(stored);
 }
 
@@ -353,7 +427,9 @@ __device__ __forceinline__ void refresh_issue(const uint32_t* gmax_block_group, 
 __device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift, int gshift_k, int lane) {
     const uint32_t* st = reinterpret_cast<const uint32_t*>(gstage) + lane;
     uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, b4 = 0xFFFFFFFFu;
-#pragma unroll 4
+    // fully unrolled: all 64 reads are in flight together (ONE LDS round trip; four iterations per trip took four,
+    // and the other seven waves of the workgroup wait at the phase's barrier for this one)
+#pragma unroll
     for (int c = 0; c < GMAX_COLS; c += 4) {
         const uint32_t v0 = st[c * 64], v1 = st[(c + 1) * 64], v2 = st[(c + 2) * 64], v3 = st[(c + 3) * 64];
         const uint32_t p0 = max(v0, v1), p1 = max(v2, v3);

@@ -66,10 +66,73 @@ constexpr int NSLICEP = BNP / GSLICE_Q;
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+// In-kernel phase timing (make KNOBS=1 STAMPS=1|2, SQE_DBG bit 32): core-clock stamps (s_memtime) around the
+// steady-state phases of the middle half-steps, summed per wave; workgroups 0 and 100 write their sums at the end
+// (api.hip prints them).  STAMPS=1 stamps the compute side only (it waits at the barrier anyway).
+#ifdef SQE_PHASE_STAMPS
+struct PhaseClock {
+    unsigned long long cmp = 0, cmp_bar = 0, mem_issue = 0, mem_reads = 0, mem_wait = 0, mem_bar = 0, phases = 0;
+    // tile boundary, group 0: [0] first compute phase, [1] barrier, [2] memory phase, [3] barrier, [4] last compute phase
+    // (with the fast-path test), [5] barrier, [6] memory phase of the next tile's first half-step, [7] barrier,
+    // [8] tile_end (common slow phase), [9] middle half-steps that took the general memory phase (whole half-step),
+    // [10] their number, [11] tiles
+    unsigned long long bnd[12] = {};
+    // tile_end: [0] read of the survivor mark, [1] own slow path, [2] barrier, [3] entry_sync, [4] times this wave had a
+    // flagged group, [5] times the common phase ran
+    unsigned long long te[6] = {};
+};
+#define PP_STAMP(var)                                  \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        var = __builtin_readcyclecounter();            \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+#define PP_DECL(...) unsigned long long __VA_ARGS__
+#define PP_ACC(...) \
+    do {            \
+        __VA_ARGS__; \
+    } while (0)
+#else
+#define PP_STAMP(var) \
+    do {              \
+    } while (0)
+#define PP_DECL(...) \
+    do {             \
+    } while (0)
+#define PP_ACC(...) \
+    do {            \
+    } while (0)
+#endif
+// stamps inside the memory phase lengthen it (each is an s_memtime the next use waits for): only with STAMPS=2
+#if defined(SQE_PHASE_STAMPS) && SQE_PHASE_STAMPS >= 2
+#define PP_STAMP_MEM(var) PP_STAMP(var)
+#elif defined(SQE_PHASE_STAMPS)
+#define PP_STAMP_MEM(var) \
+    do {                  \
+        var = 0;          \
+    } while (0)
+#else
+#define PP_STAMP_MEM(var) \
+    do {                  \
+    } while (0)
+#endif
+
+// Waits the compiler can see (gfx9 encoding: vmcnt in [3:0] and [15:14], expcnt [6:4] left at its maximum, lgkmcnt
+// [11:8]): after them hipcc knows its own LDS reads have returned and adds no s_waitcnt of its own behind them.
+#define PP_WAIT(imm)                               \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_waitcnt(imm);           \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+#define PP_WAIT_VM8_LGKM0() PP_WAIT(0x0078)
+#define PP_WAIT_VM7_LGKM0() PP_WAIT(0x0077)
+#define PP_WAIT_VM0_LGKM0() PP_WAIT(0x0070)
+
+// DMA pieces go out through inline asm (common.h: lds_dma16): hipcc does not see them, so it never guards an LDS
+// read with an s_waitcnt vmcnt(0) of its own (it did, depending on the shape of the surrounding control flow --
+// a drained ring every phase).  Every wait for a piece in this kernel is an explicit counted s_waitcnt.
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) { lds_dma16(src, lds_wave_base); }
 
 typedef bf16x8 AOps[8];   // [fm]: 128 rows x 32 k
 typedef bf16x8 BOps[4];   // [fn]:  64 queries x 32 k
@@ -89,13 +152,16 @@ struct PP {
     int wave, wm, wn;
     int tile_begin, nt, HS, J;
     long long tile_bytes;
-    int kp, trig, gshift, gshift_k, refresh_every;
+    int kp, trig, gshift, gshift_k, refresh_mask;   // refresh_mask + 1: half-steps between bound fetches early in a chunk (power of two)
     Cursor rd;                             // half-step the next MEM phase reads
     Cursor dm;                             // half-step the next MEM phase fetches (rd + 3)
     int refresh_pending, refresh_ctr, refresh_j;
     int lean_until;                        // MEM phases of half-steps < lean_until take the lean form
     bool no_mma, no_dma, no_filter;
     bool bound_on;                         // some cross-chunk bound is in use (kp-row and / or k-row)
+    int order;                             // how this wave lines up its DMA pieces and operand reads (dma_and_reads)
+    int pend_h, pend_stage;                // query piece 1 of a half-step left for this wave's next compute phase (pend_h < 0: none)
+    bool defer_on;
 
     __device__ __forceinline__ void advance(Cursor& c) const {
         if (++c.h == HS) {
@@ -120,10 +186,10 @@ struct PP {
         if (piece == 0) glds16(bs + offB0, st + wave * 1024);
         else glds16(bs + offB1, st + (wave + 8) * 1024);
     }
-    __device__ __forceinline__ void issue(const Cursor& c, int stage) const {
+    __device__ __forceinline__ void issue(const Cursor& c, int stage, bool all = true) const {
         issue_a(c, stage);
         issue_b(c.h, stage, 0);
-        issue_b(c.h, stage, 1);
+        if (all) issue_b(c.h, stage, 1);
     }
 };
 
@@ -139,6 +205,25 @@ __device__ __forceinline__ void cmp_phase(f32x4 (&acc)[8][4], const AOps& a, con
         for (int fn = 0; fn < 4; ++fn)
             acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 a[fm], b[fn], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn], 0, 0, 0);
+}
+
+// Middle compute phase that also issues the one DMA piece its wave's preceding memory phase left over (mem_lean,
+// defer): the memory phase is the longer of the two (4 pieces at ~70 cycles of issue each + 12 reads against 32
+// MFMAs), one piece among the MFMAs costs the matrix pipe less than it costs the memory phase.
+__device__ __forceinline__ void cmp_phase_mid(PP& P, f32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+        if (fm == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (P.pend_h >= 0) {
+                P.issue_b(P.pend_h, P.pend_stage, 1);
+                P.pend_h = -1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+    }
 }
 
 // Fast-path test in the INTEGER domain: for scores compared against a threshold t >= 0, "some score >= t" is
@@ -202,15 +287,45 @@ __device__ __forceinline__ void entry_sync(const PP& P, const Filter& f, int fin
     } else {
         const int any_flag = __builtin_amdgcn_readfirstlane(__any(f.flags[fl & 7] != 0));
         if (any_flag) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my appended keys are in memory
+            PP_WAIT_VM0_LGKM0();                                          // my appended keys are in memory
             PP_BARRIER();
             if (__builtin_amdgcn_readfirstlane(f.flags[P.wave]) != 0) compact_owned(f, P.wave * 32, 32, P.trig, P.kp, fl);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // a wait hipcc can see: the list loads of the sweep are retired HERE, so no path back to the loop
+            // carries a pending load and no s_waitcnt vmcnt(0) appears in front of the next tile's MFMAs
+            PP_WAIT_VM0_LGKM0();
             PP_BARRIER();                                                 // sweeps done before flags are cleared
             if (fl == 0) f.flags[P.wave] = 0;
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// operands of half-step j: 12 ds_read_b128 from stage j & 3
+__device__ __forceinline__ void read_operands(const PP& P, AOps& a, BOps& b, int j) {
+    const char* st = P.smem + (j & 3) * STAGE_BYTES;
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + P.rdA + fm * 2048);
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + P.rdB + fn * 2048);
+}
+
+// The work of a memory phase on the two shared units of the CU: this wave's 4 DMA pieces of half-step j + 3 (the
+// address unit takes 16 cycles per 1-KiB piece) and its 12 operand reads of half-step j (the LDS takes 4 cycles per
+// ds_read_b128).  The four waves of a group are in this phase together; P.order picks how a wave lines the two up:
+//   0  pieces, then reads        1  reads, then pieces
+// With every wave in order 0 (r01) all four queue at the address unit and then at the LDS, 256 + 192 cycles in a
+// row; the default gives waves 0, 1 (4, 5) of a group order 0 and waves 2, 3 (6, 7) order 1, so that the two
+// units work side by side (measured at 10 M x 1024, batch 1024: 18.53 / 18.39 / 18.43 / 18.19 ms for all-0 / all-1 /
+// stagger by parity / stagger by pairs).
+__device__ __forceinline__ void dma_and_reads(const PP& P, AOps& a, BOps& b, int j, bool dma, bool all = true) {
+    const int stage = (j + 3) & 3;
+    if (P.order == 0) {
+        if (dma) P.issue(P.dm, stage, all);
+        read_operands(P, a, b, j);
+    } else {
+        read_operands(P, a, b, j);
+        if (dma) P.issue(P.dm, stage, all);
+    }
 }
 
 // MEMORY phase of half-step j (P.rd): bound work that is due, DMA of half-step j + 3, operand reads.
@@ -227,39 +342,34 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     // (when every chunk has published its boot maxima), then every slice once per tile while the
     // bound still moves fast, one slice per tile later.  At least 4 half-steps between fetches.
     if (P.bound_on && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && j >= P.refresh_j + 4) {
+        // ... and from tile 128 on -- the bound moves by 1 / t per tile by then -- one slice every second tile
         const bool want = P.rd.e == 1 ? (P.rd.h >= P.HS / 4 && P.refresh_ctr < NSLICEP)
-                                      : (P.rd.e <= 32 ? (P.rd.h % P.refresh_every) == 0 : P.rd.h == 0);
+                                      : (P.rd.e <= 32 ? (P.rd.h & P.refresh_mask) == 0
+                                                      : (P.rd.h == 0 && (P.rd.e <= 128 || (P.rd.e & 1) == 0)));
         if (want) {
             P.refresh_pending = P.refresh_ctr % NSLICEP;
             ++P.refresh_ctr;
             P.refresh_j = j;
-            refresh_issue(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
+            refresh_issue<true>(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
         }
     }
 
-    // ---- DMA of half-step j + 3 into the stage of half-step j - 1
-    if (more) P.issue(P.dm, (j + 3) & 3);
-
-    // ---- operands of half-step j
-    {
-        const char* st = P.smem + (j & 3) * STAGE_BYTES;
-#pragma unroll
-        for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + P.rdA + fm * 2048);
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + P.rdB + fn * 2048);
-    }
+    // ---- DMA of half-step j + 3 into the stage of half-step j - 1, operands of half-step j
+    dma_and_reads(P, a, b, j, more);
 
     // ---- retire the DMA of half-step j + 1 (two MEM phases old); j + 2 and j + 3 stay in flight.
     // Anything else this wave issued in between (bound fetch, appended keys) only makes the wait
     // retire part of j + 2 as well.
-    if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    if (!more) PP_WAIT_VM0_LGKM0();
+    else PP_WAIT_VM8_LGKM0();
 
-    // ---- first half-step that needs this (general) form again; until then mem_lean runs
+    // ---- first half-step that needs this (general) form again; until then mem_lean runs.  (No division here: this
+    // bookkeeping runs in every general phase, and two integer modulos by a run-time value cost it ~450 cycles.)
     int next = j + 1;
-    if (P.refresh_pending < 0 && P.rd.e >= 2) {
-        if (!P.bound_on || P.no_filter || P.rd.e > 32) next = P.J;          // next fetch: a FILTER phase
-        else next = j + (P.refresh_every - (P.rd.h % P.refresh_every));
+    if (P.refresh_pending >= 0) next = max(j + 1, P.refresh_j + 3);           // the fetch in flight is folded then
+    else if (P.rd.e >= 2) {
+        if (!P.bound_on || P.no_filter || P.rd.e > 32) next = P.J;               // next fetch: a tile's first half-step
+        else next = j + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask));
     }
     P.lean_until = P.no_dma ? 0 : min(next, P.J - 3);
 
@@ -268,14 +378,33 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
 }
 
 // MEMORY phase without filter or bound work, j + 3 < J: the steady-state form.
-__device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j) {
-    P.issue(P.dm, (j + 3) & 3);
-    const char* st = P.smem + (j & 3) * STAGE_BYTES;
-#pragma unroll
-    for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + P.rdA + fm * 2048);
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + P.rdB + fn * 2048);
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#ifdef SQE_PHASE_STAMPS
+__device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j, bool defer, PhaseClock& pc) {
+    unsigned long long t0, t1, t2, t3;
+    PP_STAMP_MEM(t0);
+#else
+__device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j, bool defer) {
+#endif
+    // defer: three pieces here, the fourth (query piece 1) from this wave's next compute phase (cmp_phase_mid).  The
+    // wait still retires half-step j + 1 -- all four of its pieces are older than anything issued here -- and
+    // leaves the four of j + 2 and the three of j + 3 in flight.
+    if (defer) {
+        dma_and_reads(P, a, b, j, true, false);
+        P.pend_h = P.dm.h;
+        P.pend_stage = (j + 3) & 3;
+        PP_STAMP_MEM(t1);
+        PP_STAMP_MEM(t2);
+        PP_WAIT_VM7_LGKM0();
+    } else {
+        dma_and_reads(P, a, b, j, true, true);
+        PP_STAMP_MEM(t1);
+        PP_STAMP_MEM(t2);
+        PP_WAIT_VM8_LGKM0();
+    }
+    PP_STAMP_MEM(t3);
+#ifdef SQE_PHASE_STAMPS
+    pc.mem_issue += t1 - t0; pc.mem_reads += t2 - t1; pc.mem_wait += t3 - t2; ++pc.phases;
+#endif
     P.advance(P.rd);
     P.advance(P.dm);
 }
@@ -285,7 +414,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-#ifdef SQE_FILTER_COUNTERS
+#ifdef SQE_DEBUG_KNOBS
     const long long clk0 = clock64(), wall0 = wall_clock64();     // core-clock and constant-rate ticks (SQE_DBG bit 32)
 #endif
     PP P;
@@ -293,6 +422,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     const int group = P.wave >> 2;           // waves w and w + 4 share a SIMD
     P.wm = P.wave >> 2;
     P.wn = P.wave & 3;
+    P.order = (P.wave >> 1) & 1;
+    P.pend_h = -1;
+    P.pend_stage = 0;
+    P.defer_on = true;
     P.smem = smem;
     P.gstage = smem + OFF_F + FLP::OFF_GSTAGE;
 
@@ -313,10 +446,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
     P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
     P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift; P.gshift_k = p.gshift_k;
-    P.refresh_every = P.HS >= NSLICEP ? P.HS / NSLICEP : 1;
+    {
+        int every = 1;
+        while (every * 2 * NSLICEP <= P.HS) every *= 2;           // largest power of two <= HS / NSLICEP
+        P.refresh_mask = every - 1;
+    }
     P.no_mma = (SQE_DBG_BITS(p) & 1) != 0; P.no_dma = (SQE_DBG_BITS(p) & 2) != 0; P.no_filter = (SQE_DBG_BITS(p) & 4) != 0;
     if (SQE_DBG_BITS(p) & 8) P.gshift = P.gshift_k = -1;
     if (SQE_DBG_BITS(p) & 64) P.gshift_k = -1;          // kp-row bound only (the r01 filter)
+    if (SQE_DBG_BITS(p) & 128) P.order = 0;             // every wave: pieces, then reads (the r01 order)
+    if (SQE_DBG_BITS(p) & 256) P.order = 1;             // every wave: reads, then pieces
+    if (SQE_DBG_BITS(p) & 512) P.order = P.wave & 1;    // stagger by wave parity instead of pairs
+    if (SQE_DBG_BITS(p) & 1024) P.defer_on = false;     // all four DMA pieces from the memory phase
     P.bound_on = P.gshift >= 0 || P.gshift_k >= 0;
 
     Filter f;
@@ -377,7 +518,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
             P.advance(P.dm);
         }
     }
-    __syncthreads();                       // vmcnt(0) + barrier: prologue landed, state initialised
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's pieces (inline asm: the compiler does not wait for them)
+    __syncthreads();                       // prologue landed, state initialised
 
     {
         //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [SLOW(e) sync] | CMP(e+1,0) | MEM(e+1,1) ..
@@ -385,6 +527,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
         if (P.J > 0) {
             const int HS = P.HS;
             int j = 0;
+#ifdef SQE_PHASE_STAMPS
+            PhaseClock pclk;
+#endif
             unsigned cols = 0;                 // column groups of the finished tile that hold a survivor
             int thr[4];
             int* any_cols = f.flags + 8;       // some wave of the workgroup marked a survivor in this tile
@@ -400,41 +545,76 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
             // after the barrier that ends G1's last compute phase of entry e: every wave takes the same path
             auto tile_end = [&](int e) {
                 if (P.no_filter) return;
+                PP_DECL(e0, e1, e2, e3, e4);
+                PP_STAMP(e0);
                 const bool any = e == 0 || __builtin_amdgcn_readfirstlane(*any_cols) != 0;
                 if (!any) return;
                 const int fl = fresh_lane();
+                PP_STAMP(e1);
                 if (e == 0) filter_boot<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl);
                 else if (cols) filter_tile<8, 4>(acc, f, P.row0_of(e), P.wm * 128, P.wn * 64, fl, cols);
                 __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP(e2);
                 PP_BARRIER();
+                PP_STAMP(e3);
                 if (tid == 0) *any_cols = 0;   // read again a whole tile (2 * HS barriers) later
                 entry_sync(P, f, e);
+                PP_STAMP(e4);
+                PP_ACC(pclk.te[0] += e1 - e0; pclk.te[1] += e2 - e1; pclk.te[2] += e3 - e2; pclk.te[3] += e4 - e3; pclk.te[4] += (cols != 0); ++pclk.te[5]);
             };
             if (group == 0) {
                 mem_phase(P, f, a, b, 0);
                 PP_BARRIER();
                 for (int e = 0; e < n_entries; ++e) {
+                    PP_DECL(b0, b1, b2, b3, b4, b5, b6, b7, b8, b9);
+                    PP_STAMP(b0);
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
+                    PP_STAMP(b1);
                     PP_BARRIER();
+                    PP_STAMP(b2);
                     mem_phase(P, f, a, b, j + 1);
                     if (HS == 2) load_thr();
+                    PP_STAMP(b3);
                     PP_BARRIER();
+                    PP_STAMP(b4);
+                    PP_ACC(pclk.bnd[0] += b1 - b0; pclk.bnd[1] += b2 - b1; pclk.bnd[2] += b3 - b2; pclk.bnd[3] += b4 - b3; ++pclk.bnd[11]);
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
-                        if (!P.no_mma) cmp_phase<false>(acc, a, b);
+                        PP_DECL(s0, s1, s2, s3, s4);
+                        PP_STAMP(s0);
+                        if (!P.no_mma) cmp_phase_mid(P, acc, a, b);
+                        PP_STAMP(s1);
                         PP_BARRIER();
-                        if (j + 1 < P.lean_until) mem_lean(P, a, b, j + 1);
+                        PP_STAMP(s2);
+                        const bool lean = j + 1 < P.lean_until;
+                        const bool defer = P.defer_on && h < HS - 2;      // the next compute phase is a middle one
+#ifdef SQE_PHASE_STAMPS
+                        if (lean) mem_lean(P, a, b, j + 1, defer, pclk);
+#else
+                        if (lean) mem_lean(P, a, b, j + 1, defer);
+#endif
                         else mem_phase(P, f, a, b, j + 1);
                         if (h == HS - 2) load_thr();
+                        PP_STAMP_MEM(s3);
                         PP_BARRIER();
+                        PP_STAMP(s4);
+                        PP_ACC(if (lean) { pclk.cmp += s1 - s0; pclk.cmp_bar += s2 - s1; pclk.mem_bar += s4 - s3; }
+                               else { pclk.bnd[9] += s4 - s0; ++pclk.bnd[10]; });
                         ++j;
                     }
+                    PP_STAMP(b4);
                     last_phase();
+                    PP_STAMP(b5);
                     PP_BARRIER();
+                    PP_STAMP(b6);
                     if (e + 1 < n_entries) mem_phase(P, f, a, b, j + 1);
+                    PP_STAMP(b7);
                     PP_BARRIER();
+                    PP_STAMP(b8);
                     ++j;
                     if (e + 1 < n_entries) tile_end(e);
+                    PP_STAMP(b9);
+                    PP_ACC(pclk.bnd[4] += b5 - b4; pclk.bnd[5] += b6 - b5; pclk.bnd[6] += b7 - b6; pclk.bnd[7] += b8 - b7; pclk.bnd[8] += b9 - b8);
                 }
             } else {
                 PP_BARRIER();
@@ -445,15 +625,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
-                        if (j < P.lean_until) mem_lean(P, a, b, j);
+#ifdef SQE_PHASE_STAMPS
+                        unsigned long long s0, s1, s2, s3;
+                        const bool lean = j < P.lean_until;
+                        if (lean) mem_lean(P, a, b, j, P.defer_on, pclk);
+                        else mem_phase(P, f, a, b, j);
+                        PP_STAMP_MEM(s0);
+                        PP_BARRIER();
+                        PP_STAMP(s1);
+                        if (!P.no_mma) cmp_phase_mid(P, acc, a, b);
+                        PP_STAMP(s2);
+                        PP_BARRIER();
+                        PP_STAMP(s3);
+                        if (lean) { pclk.mem_bar += s1 - s0; pclk.cmp += s2 - s1; pclk.cmp_bar += s3 - s2; }
+#else
+                        if (j < P.lean_until) mem_lean(P, a, b, j, P.defer_on);
                         else mem_phase(P, f, a, b, j);
                         PP_BARRIER();
-                        if (!P.no_mma) cmp_phase<false>(acc, a, b);
+                        if (!P.no_mma) cmp_phase_mid(P, acc, a, b);
                         PP_BARRIER();
+#endif
                         ++j;
                     }
-                    if (j < P.lean_until) mem_lean(P, a, b, j);
+#ifdef SQE_PHASE_STAMPS
+                    { PhaseClock scratch; if (j < P.lean_until) mem_lean(P, a, b, j, false, scratch); else mem_phase(P, f, a, b, j); }
+#else
+                    if (j < P.lean_until) mem_lean(P, a, b, j, false);
                     else mem_phase(P, f, a, b, j);
+#endif
                     load_thr();
                     PP_BARRIER();
                     last_phase();
@@ -462,6 +661,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     if (e + 1 < n_entries) tile_end(e);
                 }
             }
+#ifdef SQE_PHASE_STAMPS
+            if (f.dbg_counters && (blockIdx.x == 0 || blockIdx.x == 100) && lane == 0) {
+                unsigned long long* o = f.dbg_counters + 8 + (blockIdx.x ? 64 : 0) + P.wave * 8;
+                o[0] = pclk.phases; o[1] = pclk.cmp; o[2] = pclk.cmp_bar; o[3] = pclk.mem_issue;
+                o[4] = pclk.mem_reads; o[5] = pclk.mem_wait; o[6] = pclk.mem_bar;
+                if (P.wave == 0)
+                    for (int i = 0; i < 12; ++i) f.dbg_counters[8 + 128 + (blockIdx.x ? 16 : 0) + i] = pclk.bnd[i];
+                for (int i = 0; i < 6; ++i) f.dbg_counters[8 + 160 + (blockIdx.x ? 48 : 0) + P.wave * 6 + i] = pclk.te[i];
+            }
+#endif
         }
     }
 
@@ -475,10 +684,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     __syncthreads();
     for (int i = tid; i < BNP; i += SCAN_THREADS)
         p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = f.cnt[i];
-#ifdef SQE_FILTER_COUNTERS
-    if (f.dbg_counters && blockIdx.x == 0 && tid == 0) {
-        f.dbg_counters[4] = (unsigned long long)(clock64() - clk0);
-        f.dbg_counters[5] = (unsigned long long)(wall_clock64() - wall0);
+#ifdef SQE_DEBUG_KNOBS
+    if (p.dbg_counters && (SQE_DBG_BITS(p) & 32) && blockIdx.x == 0 && tid == 0) {
+        p.dbg_counters[4] = (unsigned long long)(clock64() - clk0);
+        p.dbg_counters[5] = (unsigned long long)(wall_clock64() - wall0);
     }
 #endif
 }
