@@ -125,6 +125,7 @@ struct GemmArgs {
     int splits;           // split-K factor (ring kernel, EPI_RESID only): split s writes its partial sum to
     size_t split_stride;  //   out + s * split_stride floats; bias and residual are added by split 0
     int t_tiles;
+    int pp_stagger;       // gemm_pp_kernel: half of a group's waves read their operands before they issue their DMA pieces
 };
 
 // Block tile: (2*FM*16) output features x (4*FN*16) tokens, 8 waves as 2 (features) x 4 (tokens).
@@ -420,10 +421,9 @@ constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;       // 128 KiB
 typedef bf16x8 AOps[8];
 typedef bf16x8 BOps[4];
 struct Cursor { int e, h; const char* a; const char* b; };
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+// DMA pieces through inline asm (common.h: lds_dma16), as in scan_pp.hip: hipcc does not see them and so never puts an
+// s_waitcnt vmcnt(0) of its own in front of an LDS read; every wait for a piece is an explicit counted one.
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) { lds_dma16(src, lds_wave_base); }
 #define GPP_BARRIER()                          \
     do {                                       \
         __builtin_amdgcn_sched_barrier(0);     \
@@ -511,14 +511,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     f32x4 acc[8][4];
     AOps a;
     BOps b;
-    auto mem_phase = [&](int j) {
-        const bool more = j + 3 < J;
-        if (more) issue(dm, (j + 3) & 3);
+    // waves 0, 1 (4, 5) of a group issue their DMA pieces first and read their operands after, waves 2, 3 (6, 7) the
+    // other way round: the address unit and the LDS then work side by side (scan_pp.hip: dma_and_reads)
+    const bool reads_first = p.pp_stagger && ((wave >> 1) & 1);
+    auto read_operands = [&](int j) {
         const char* st = smem + (j & 3) * STAGE_BYTES;
 #pragma unroll
         for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + rdA + fm * 2048);
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + rdB + fn * 2048);
+    };
+    auto mem_phase = [&](int j) {
+        const bool more = j + 3 < J;
+        if (reads_first) {
+            read_operands(j);
+            if (more) issue(dm, (j + 3) & 3);
+        } else {
+            if (more) issue(dm, (j + 3) & 3);
+            read_operands(j);
+        }
         // retire the DMA of half-step j + 1; j + 2 and j + 3 stay in flight, and so do the 32 epilogue stores for
         // the two memory phases after an epilogue (they are younger than the half-step that has to land)
         if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -589,7 +600,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         issue(dm, s);
         advance(dm);
     }
-    __syncthreads();                       // vmcnt(0) + barrier: prologue landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's pieces (inline asm: the compiler does not wait for them)
+    __syncthreads();                       // prologue landed
 
     int j = 0;
     if (group == 0) {
@@ -642,6 +654,8 @@ int launch_gemm_pp(const GemmArgs& a, int t_pad, int cu_count, hipStream_t strea
     p.n_tiles = a.N / 256;
     p.t_tiles = t_pad / 256;
     p.splits = 1; p.split_stride = 0;
+    static const int stagger = [] { const char* e = knob_env("SQE_GEMM_STAGGER"); return e ? atoi(e) : 1; }();   // knobs build: A/B
+    p.pp_stagger = stagger;
     const int tiles = p.n_tiles * p.t_tiles;
     auto kern = gemm_pp_kernel<EPI>;
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), gpp::LDS_BYTES));

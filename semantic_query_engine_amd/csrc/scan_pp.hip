@@ -316,7 +316,7 @@ __device__ __forceinline__ void read_operands(const PP& P, AOps& a, BOps& b, int
 // With every wave in order 0 (r01) all four queue at the address unit and then at the LDS, 256 + 192 cycles in a
 // row; the default gives waves 0, 1 (4, 5) of a group order 0 and waves 2, 3 (6, 7) order 1, so that the two
 // units work side by side (measured at 10 M x 1024, batch 1024: 18.53 / 18.39 / 18.43 / 18.19 ms for all-0 / all-1 /
-// stagger by parity / stagger by pairs).
+// stagger by parity / stagger by pairs; four reads then a piece, repeated, in every wave: slower than all of them).
 __device__ __forceinline__ void dma_and_reads(const PP& P, AOps& a, BOps& b, int j, bool dma, bool all = true) {
     const int stage = (j + 3) & 3;
     if (P.order == 0) {
