@@ -217,6 +217,9 @@ def test_concurrent_searches_share_one_batched_scan():
 
     async def many():
         app = shim.create_app(oc, None, DIM)
+        # the product's window is 1 ms; parsing 32 bodies of 1024 floats on a loaded test box can take longer than
+        # that, and what is tested here is the batching, not the host's speed
+        app.state.search_batcher.max_wait = 0.5
         import httpx
         async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://shim") as ac:
             rs = await asyncio.gather(*[ac.post("/idx/_search", json={"size": ks[i], "query": {"knn": {"embedding": {
