@@ -114,6 +114,26 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
     return __builtin_elementwise_fma(es, v * 0.5f, v * 0.5f);          // 0.5 v (1 + erf)
 }
 
+// GELU for the large-batch GEMM epilogue, where it is the cost (128 values per lane, VALU-issue-bound: the erf form
+// above is ~36 issue slots per pair of values, four of them transcendental): 0.5 x (1 + erf(x / sqrt 2)) =
+// x (0.5 + h(x)), h odd; h(x) ~ x Q(x^2) with a degree-13 odd polynomial fitted on |x| <= 4 (weighted so that
+// |x| |h error| is minimised), x clamped to [-4, 4] inside h, and the fit pinned so that this fp32 evaluation gives
+// h(4) = 0.5 EXACTLY: beyond the clamp GELU is x or 0 exactly, however large |x| is.  12 issue slots per pair, no
+// transcendental.  |GELU_poly - GELU_erf| <= 1.9e-4 absolute for every x (tools/gelu_fit.py makes the fit and prints
+// the error of the fp32 evaluation); the output is rounded to bf16 (2^-9 relative) right after.
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 v) {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(v[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(v[1], -4.0f, 4.0f)};
+    const f32x2 t = xc * xc;
+    f32x2 q = __builtin_elementwise_fma(f32x2{2.258820153144825e-08f, 2.258820153144825e-08f}, t, f32x2{-1.5888268762864755e-06f, -1.5888268762864755e-06f});
+    q = __builtin_elementwise_fma(q, t, f32x2{4.776388232130557e-05f, 4.776388232130557e-05f});
+    q = __builtin_elementwise_fma(q, t, f32x2{-0.000812187441624701f, -0.000812187441624701f});
+    q = __builtin_elementwise_fma(q, t, f32x2{0.00876369047909975f, 0.00876369047909975f});
+    q = __builtin_elementwise_fma(q, t, f32x2{-0.06455441564321518f, -0.06455441564321518f});
+    q = __builtin_elementwise_fma(q, t, f32x2{0.39787042140960693f, 0.39787042140960693f});
+    const f32x2 h = q * xc;
+    return __builtin_elementwise_fma(v, h, v * 0.5f);
+}
+
 struct GemmArgs {
     const bf16_t* W;      // [N, K] row-major (torch Linear weight)
     const bf16_t* X;      // [T_pad, K]
@@ -126,6 +146,7 @@ struct GemmArgs {
     size_t split_stride;  //   out + s * split_stride floats; bias and residual are added by split 0
     int t_tiles;
     int pp_stagger;       // gemm_pp_kernel: half of a group's waves read their operands before they issue their DMA pieces
+    int pp_dbg;           // gemm_pp_kernel, knobs build, timing only (results wrong): 1 = no bias loads, 2 = no stores
 };
 
 // Block tile: (2*FM*16) output features x (4*FN*16) tokens, 8 waves as 2 (features) x 4 (tokens).
@@ -234,8 +255,16 @@ __device__ __forceinline__ void store_b64_asm(void* p, uint2 v) {
     w.x = v.x; w.y = v.y;
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(w) : "memory");
 }
+__device__ __forceinline__ void store_b128_asm(void* p, uint4 v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 w;
+    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    // s_nop: a store of more than 8 bytes must not read its data registers in the two wait states after a VALU wrote
+    // them; hipcc pads its own stores, but cannot see into an asm block (without the nop: garbage in the output)
+    asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+}
 __device__ __forceinline__ void store_f4_asm(void* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 template <int EPI>
@@ -417,7 +446,9 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
 // issue order).
 namespace gpp {
 constexpr int HALF_K = 32, LINE_BYTES = 128, OPER_BYTES = 128 * LINE_BYTES, STAGE_BYTES = 2 * OPER_BYTES, NSTAGE = 4;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;       // 128 KiB
+constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;      // 128 KiB
+constexpr int MAX_BIAS_N = 4096;                      // the bias vector sits in LDS behind the ring
+constexpr int LDS_BYTES = RING_BYTES + MAX_BIAS_N * 4;
 typedef bf16x8 AOps[8];
 typedef bf16x8 BOps[4];
 struct Cursor { int e, h; const char* a; const char* b; };
@@ -440,10 +471,35 @@ __device__ __forceinline__ void cmp_phase(f32x4 (&acc)[8][4], const AOps& a, con
 }
 }  // namespace gpp
 
+// Phase timing of the ping-pong GEMM (make KNOBS=1 STAMPS=1, SQE_GEMM_DBG bit 4): core-clock sums of workgroup 0,
+// waves 0 (group 0) and 4 (group 1): [0] tiles, [1] kernel, [2] epilogue, [3] memory phase after the epilogue,
+// [4] barrier after it, [5] steady compute phases, [6] barriers after them, [7] steady phases counted
+#ifdef SQE_PHASE_STAMPS
+__device__ unsigned long long g_gemm_clk[2][8];
+#define GPP_STAMP(var)                                 \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        var = __builtin_readcyclecounter();            \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+#define GPP_ACC(...) \
+    do {             \
+        __VA_ARGS__; \
+    } while (0)
+#else
+#define GPP_STAMP(var) \
+    do {               \
+    } while (0)
+#define GPP_ACC(...) \
+    do {             \
+    } while (0)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     using namespace gpp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = reinterpret_cast<float*>(smem + RING_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2, wm = wave >> 2, wn = wave & 3;
@@ -471,13 +527,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 
     // per-lane DMA source offsets (piece t covers LDS lines 8t .. 8t+7; line L holds the slices of tile rows L
     // and L + 128, chunk positions XOR-swizzled by (L >> 1) & 7) and operand read offsets: as scan_pp.hip
-    unsigned off0, off1, rdA, rdB;
+    unsigned off0, off1, offA0, offA1, rdA, rdB;
     {
         const int line = wave * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((line >> 1) & 7);
         const int row = line + 128 * (c >> 2);
         off0 = (unsigned)(row * ld) + (c & 3) * 16;
         off1 = off0 + (unsigned)(64 * ld);
+        // Weight rows enter the tile PERMUTED inside each 128-row half: tile row p = i * 16 + g * 4 + r (fragment i,
+        // lane group g, accumulator element r) holds feature (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r, so that a lane's
+        // fragments 2s and 2s + 1 are EIGHT consecutive features of its token: one 16-byte store, and the four lane
+        // groups of a store cover 64 contiguous bytes of a token row (32-byte segments cost the epilogue ~300 cycles
+        // per store instruction).  Only the source row of the DMA changes; the LDS image and the reads do not.
+        auto wrow = [&](int tr) {
+            const int pr = tr & 127, i = pr >> 4, g = (pr >> 2) & 3, r = pr & 3;
+            if (p.pp_dbg & (16 | 32)) return tr;
+            return (tr & 128) + (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
+        };
+        offA0 = (unsigned)(wrow(row) * ld) + (c & 3) * 16;
+        offA1 = (unsigned)(wrow(row + 64) * ld) + (c & 3) * 16;
         const int r = lane & 15, cq = lane >> 4, sw = (r >> 1) & 7;
         rdA = (unsigned)(r * LINE_BYTES + (((wm * 4 + cq) ^ sw) << 4));
         rdB = (unsigned)(((wn & 1) * 64 + r) * LINE_BYTES + ((((wn >> 1) * 4 + cq) ^ sw) << 4));
@@ -498,8 +566,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         char* st = smem + stage * STAGE_BYTES;
         const char* as = c.a + c.h * (HALF_K * 2);
         const char* bs = c.b + c.h * (HALF_K * 2);
-        glds16(as + off0, st + wave * 1024);
-        glds16(as + off1, st + (wave + 8) * 1024);
+        glds16(as + offA0, st + wave * 1024);
+        glds16(as + offA1, st + (wave + 8) * 1024);
         glds16(bs + off0, st + OPER_BYTES + wave * 1024);
         glds16(bs + off1, st + OPER_BYTES + (wave + 8) * 1024);
     };
@@ -530,10 +598,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
             if (more) issue(dm, (j + 3) & 3);
             read_operands(j);
         }
-        // retire the DMA of half-step j + 1; j + 2 and j + 3 stay in flight, and so do the 32 epilogue stores for
+        // retire the DMA of half-step j + 1; j + 2 and j + 3 stay in flight, and so do the 16 epilogue stores for
         // the two memory phases after an epilogue (they are younger than the half-step that has to land)
         if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (post_epi > 0) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+        else if (post_epi > 0) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         if (post_epi > 0) --post_epi;
         advance(rd);
@@ -545,39 +613,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         const int n0 = nt * 256, t0 = tt * 256;
         // The loads an epilogue needs are issued before its first store (a load hipcc can see makes it wait for
         // everything older, the stores included).  EPI_RESID reads 64 VGPRs of residual per wave: it goes in two
-        // halves of four feature blocks, so that the kernel keeps its accumulators and the residual in registers.
+        // halves of two fragment pairs, so that the kernel keeps its accumulators and the residual in registers.
+        // A fragment pair (2s, 2s + 1) is eight consecutive features of the lane's token (see the row permutation
+        // above): 16 stores of 16 bytes per wave.
         constexpr int HALVES = EPI == EPI_RESID ? 2 : 1;
-        constexpr int IB = 8 / HALVES;
+        constexpr int SB = 4 / HALVES;                    // fragment pairs per half
+        if (p.pp_dbg & 32) {                              // bisecting: the r02a epilogue (8-byte stores, rows not permuted)
 #pragma unroll
-        for (int half = 0; half < HALVES; ++half) {
-            uint2 res[EPI == EPI_RESID ? IB : 1][EPI == EPI_RESID ? 4 : 1];
-            float4 bias4[IB];
-#pragma unroll
-            for (int ii = 0; ii < IB; ++ii) {
-                const int i = half * IB + ii;
+            for (int i = 0; i < 8; ++i) {
                 const int n = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
-                bias4[ii] = *reinterpret_cast<const float4*>(p.bias + n);
-                if (EPI == EPI_RESID) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
-                        res[EPI == EPI_RESID ? ii : 0][EPI == EPI_RESID ? j : 0] =
-                            *reinterpret_cast<const uint2*>(p.resid + (size_t)tk * p.N + n);
-                    }
-                }
-            }
-#pragma unroll
-            for (int ii = 0; ii < IB; ++ii) {
-                const int i = half * IB + ii;
-                const int n = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
-                const float4 b4 = bias4[ii];
+                const float4 b4 = (p.pp_dbg & 64) ? *reinterpret_cast<const float4*>(p.bias + n) : *reinterpret_cast<const float4*>(bias_lds + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
-                    float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
                     const size_t o = (size_t)tk * p.N + n;
+                    float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
                     if (EPI == EPI_RESID) {
-                        const uint2 r2 = res[EPI == EPI_RESID ? ii : 0][EPI == EPI_RESID ? j : 0];
+                        const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o);
                         v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
                         v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
                     } else if (EPI == EPI_GELU) {
@@ -587,15 +639,76 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
                     uint2 w2;
                     w2.x = pack_bf16x2(v0, v1);
                     w2.y = pack_bf16x2(v2, v3);
-                    store_b64_asm(reinterpret_cast<bf16_t*>(p.out) + o, w2);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            post_epi = 0;
+            return;
+        }
+#pragma unroll
+        for (int half = 0; half < HALVES; ++half) {
+            uint4 res[EPI == EPI_RESID ? SB : 1][EPI == EPI_RESID ? 4 : 1];
+#pragma unroll
+            for (int ss = 0; ss < SB; ++ss) {
+                const int sp = half * SB + ss;
+                const int n = n0 + wm * 128 + sp * 32 + (lane >> 4) * 8;
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
+                        res[EPI == EPI_RESID ? ss : 0][EPI == EPI_RESID ? j : 0] =
+                            *reinterpret_cast<const uint4*>(p.resid + (size_t)tk * p.N + n);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ss = 0; ss < SB; ++ss) {
+                const int sp = half * SB + ss;
+                const int n = n0 + wm * 128 + sp * 32 + (lane >> 4) * 8;
+                // bias from LDS (the whole vector was copied in at kernel start): no vector-memory load in the epilogue
+                // of the bias / GELU kernels, and no registers held across it
+                float4 bq[2] = {*reinterpret_cast<const float4*>(bias_lds + n), *reinterpret_cast<const float4*>(bias_lds + n + 4)};
+                if (p.pp_dbg & 8) bq[0] = bq[1] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
+                    const size_t o = (size_t)tk * p.N + n;
+                    unsigned w[4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {         // the two fragments of the pair
+                        const int i = 2 * sp + q;
+                        const float4 b4 = bq[q];
+                        float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+                        if (EPI == EPI_RESID) {
+                            const uint4 r4 = res[EPI == EPI_RESID ? ss : 0][EPI == EPI_RESID ? j : 0];
+                            const unsigned rx = q ? r4.z : r4.x, ry = q ? r4.w : r4.y;
+                            v0 += bf16_to_f32((bf16_t)(rx & 0xffff)); v1 += bf16_to_f32((bf16_t)(rx >> 16));
+                            v2 += bf16_to_f32((bf16_t)(ry & 0xffff)); v3 += bf16_to_f32((bf16_t)(ry >> 16));
+                        } else if (EPI == EPI_GELU) {
+                            const f32x2 g01 = gelu_poly2(f32x2{v0, v1}), g23 = gelu_poly2(f32x2{v2, v3});
+                            v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+                        }
+                        w[2 * q] = pack_bf16x2(v0, v1);
+                        w[2 * q + 1] = pack_bf16x2(v2, v3);
+                    }
+                    // a plain store: hipcc may see it (the DMA pieces it must not see are asm); the same store through an asm
+                    // block (SQE_GEMM_DBG bit 256, knobs build) leaves garbage in the output -- cause not found
+                    if (p.pp_dbg & 256) store_b128_asm(reinterpret_cast<bf16_t*>(p.out) + o, uint4{w[0], w[1], w[2], w[3]});
+                    else if (!(p.pp_dbg & 2)) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) = uint4{w[0], w[1], w[2], w[3]};
                 }
             }
         }
         post_epi = 2;
+        if (p.pp_dbg & 128) {                             // bisecting: drain instead of counting across the stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            post_epi = 0;
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: half-steps 0, 1, 2
+    // ---- the bias vector into LDS (N <= MAX_BIAS_N: the launcher checks), then the prologue: half-steps 0, 1, 2
+    for (int i = tid * 4; i < p.N; i += 512 * 4) *reinterpret_cast<float4*>(bias_lds + i) = *reinterpret_cast<const float4*>(p.bias + i);
     for (int s = 0; s < 3 && s < J; ++s) {
         issue(dm, s);
         advance(dm);
@@ -604,6 +717,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     __syncthreads();                       // prologue landed
 
     int j = 0;
+#ifdef SQE_PHASE_STAMPS
+    unsigned long long k0 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, c0 = 0, c1 = 0, c2 = 0, clk[8] = {};
+#endif
+    GPP_STAMP(k0);
     if (group == 0) {
         mem_phase(0);
         GPP_BARRIER();
@@ -614,38 +731,62 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
             GPP_BARRIER();
             ++j;
             for (int h = 1; h < HS - 1; ++h) {
+                GPP_STAMP(c0);
                 cmp_phase<false>(acc, a, b);
+                GPP_STAMP(c1);
                 GPP_BARRIER();
+                GPP_STAMP(c2);
+                GPP_ACC(clk[5] += c1 - c0; clk[6] += c2 - c1; ++clk[7]);
                 mem_phase(j + 1);
                 GPP_BARRIER();
                 ++j;
             }
             cmp_phase<false>(acc, a, b);
             GPP_BARRIER();
+            GPP_STAMP(t0);
             epilogue(e);
+            GPP_STAMP(t1);
             if (j + 1 < J) mem_phase(j + 1);
+            GPP_STAMP(t2);
             GPP_BARRIER();
+            GPP_STAMP(t3);
+            GPP_ACC(clk[2] += t1 - t0; clk[3] += t2 - t1; clk[4] += t3 - t2; ++clk[0]);
             ++j;
         }
     } else {
         GPP_BARRIER();
         for (int e = 0; e < my_tiles; ++e) {
+            GPP_STAMP(t0);
             if (e > 0) epilogue(e - 1);
+            GPP_STAMP(t1);
             mem_phase(j);
+            GPP_STAMP(t2);
             GPP_BARRIER();
+            GPP_STAMP(t3);
+            GPP_ACC(if (e > 0) { clk[2] += t1 - t0; clk[3] += t2 - t1; clk[4] += t3 - t2; ++clk[0]; });
             cmp_phase<true>(acc, a, b);
             GPP_BARRIER();
             ++j;
             for (int h = 1; h < HS; ++h) {
                 mem_phase(j);
                 GPP_BARRIER();
+                GPP_STAMP(c0);
                 cmp_phase<false>(acc, a, b);
+                GPP_STAMP(c1);
                 GPP_BARRIER();
+                GPP_STAMP(c2);
+                GPP_ACC(clk[5] += c1 - c0; clk[6] += c2 - c1; ++clk[7]);
                 ++j;
             }
         }
         epilogue(my_tiles - 1);
     }
+#ifdef SQE_PHASE_STAMPS
+    if ((p.pp_dbg & 4) && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {
+        clk[1] = __builtin_readcyclecounter() - k0;
+        for (int i = 0; i < 8; ++i) g_gemm_clk[wave >> 2][i] = clk[i];
+    }
+#endif
 }
 
 template <int EPI>
@@ -656,11 +797,29 @@ int launch_gemm_pp(const GemmArgs& a, int t_pad, int cu_count, hipStream_t strea
     p.splits = 1; p.split_stride = 0;
     static const int stagger = [] { const char* e = knob_env("SQE_GEMM_STAGGER"); return e ? atoi(e) : 1; }();   // knobs build: A/B
     p.pp_stagger = stagger;
+    static const int ppdbg = [] { const char* e = knob_env("SQE_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    p.pp_dbg = ppdbg;
     const int tiles = p.n_tiles * p.t_tiles;
     auto kern = gemm_pp_kernel<EPI>;
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), gpp::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count)), dim3(512), gpp::LDS_BYTES, stream, p);
     SQE_HIP(hipGetLastError());
+#ifdef SQE_PHASE_STAMPS
+    if (p.pp_dbg & 4) {
+        static int printed[3] = {0, 0, 0};
+        if (printed[EPI]++ == 30) {                      // one launch well after warm-up, per epilogue kind
+            unsigned long long h[2][8];
+            SQE_HIP(hipStreamSynchronize(stream));
+            SQE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_clk), sizeof(h)));
+            for (int g = 0; g < 2; ++g) {
+                const double t = (double)std::max<unsigned long long>(h[g][0], 1), n = (double)std::max<unsigned long long>(h[g][7], 1);
+                fprintf(stderr, "[sqe dbg] gemm_pp<%d> N=%d K=%d group %d: kernel %llu cycles, %llu tile epilogues: epilogue %.0f, memory phase after it %.0f, "
+                                "barrier %.0f | steady compute phase %.0f + barrier %.0f (%llu phases)\n",
+                        EPI, p.N, p.K, g, h[g][1], h[g][0], h[g][2] / t, h[g][3] / t, h[g][4] / t, h[g][5] / n, h[g][6] / n, h[g][7]);
+            }
+        }
+    }
+#endif
     if (EPI == EPI_RESID && splits_out) *splits_out = 0;      // 0 partial sums: one bf16 row
     return SQE_OK;
 }
@@ -925,7 +1084,7 @@ int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, 
         // the ping-pong kernel (r02: QKV 220 -> 207 us, out-proj + FFN-down 178 -> 172 us per call at 64 x 512 tokens,
         // FFN-up + GELU equal); SQE_ENC_GEMM=0 in a knobs build picks the two-stage persistent kernel it replaced
         static const int form = [] { const char* e = knob_env("SQE_ENC_GEMM"); return e ? atoi(e) : 1; }();
-        if (!old_form && form == 1) return launch_gemm_pp<EPI>(a, t_pad, cu_count, stream, splits_out);
+        if (!old_form && form == 1 && a.N <= gpp::MAX_BIAS_N) return launch_gemm_pp<EPI>(a, t_pad, cu_count, stream, splits_out);
         if (!old_form) return launch_gemm_persistent<EPI>(a, t_pad, cu_count, stream, splits_out);
         GemmArgs p = a;
         p.splits = 1; p.split_stride = 0; p.t_tiles = 0;
