@@ -146,7 +146,7 @@ struct GemmArgs {
     size_t split_stride;  //   out + s * split_stride floats; bias and residual are added by split 0
     int t_tiles;
     int pp_stagger;       // gemm_pp_kernel: half of a group's waves read their operands before they issue their DMA pieces
-    int pp_dbg;           // gemm_pp_kernel, knobs build, timing only (results wrong): 1 = no bias loads, 2 = no stores
+    int pp_dbg;           // gemm_pp_kernel, knobs build, timing only: 2 = no stores (results wrong), 4 = phase stamps (STAMPS build)
 };
 
 // Block tile: (2*FM*16) output features x (4*FN*16) tokens, 8 waves as 2 (features) x 4 (tokens).
@@ -254,17 +254,6 @@ __device__ __forceinline__ void store_b64_asm(void* p, uint2 v) {
     u32x2 w;
     w.x = v.x; w.y = v.y;
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(w) : "memory");
-}
-__device__ __forceinline__ void store_b128_asm(void* p, uint4 v) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    u32x4 w;
-    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-    // s_nop: a store of more than 8 bytes must not read its data registers in the two wait states after a VALU wrote
-    // them; hipcc pads its own stores, but cannot see into an asm block (without the nop: garbage in the output)
-    asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
-}
-__device__ __forceinline__ void store_f4_asm(void* p, f32x4 v) {
-    asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 template <int EPI>
@@ -539,9 +528,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         // fragments 2s and 2s + 1 are EIGHT consecutive features of its token: one 16-byte store, and the four lane
         // groups of a store cover 64 contiguous bytes of a token row (32-byte segments cost the epilogue ~300 cycles
         // per store instruction).  Only the source row of the DMA changes; the LDS image and the reads do not.
-        auto wrow = [&](int tr) {
+        auto wrow = [](int tr) {
             const int pr = tr & 127, i = pr >> 4, g = (pr >> 2) & 3, r = pr & 3;
-            if (p.pp_dbg & (16 | 32)) return tr;
             return (tr & 128) + (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
         };
         offA0 = (unsigned)(wrow(row) * ld) + (c & 3) * 16;
@@ -618,34 +606,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         // above): 16 stores of 16 bytes per wave.
         constexpr int HALVES = EPI == EPI_RESID ? 2 : 1;
         constexpr int SB = 4 / HALVES;                    // fragment pairs per half
-        if (p.pp_dbg & 32) {                              // bisecting: the r02a epilogue (8-byte stores, rows not permuted)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int n = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
-                const float4 b4 = (p.pp_dbg & 64) ? *reinterpret_cast<const float4*>(p.bias + n) : *reinterpret_cast<const float4*>(bias_lds + n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
-                    const size_t o = (size_t)tk * p.N + n;
-                    float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-                    if (EPI == EPI_RESID) {
-                        const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o);
-                        v0 += bf16_to_f32((bf16_t)(r2.x & 0xffff)); v1 += bf16_to_f32((bf16_t)(r2.x >> 16));
-                        v2 += bf16_to_f32((bf16_t)(r2.y & 0xffff)); v3 += bf16_to_f32((bf16_t)(r2.y >> 16));
-                    } else if (EPI == EPI_GELU) {
-                        const f32x2 g01 = gelu_erf2(f32x2{v0, v1}), g23 = gelu_erf2(f32x2{v2, v3});
-                        v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
-                    }
-                    uint2 w2;
-                    w2.x = pack_bf16x2(v0, v1);
-                    w2.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = w2;
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            post_epi = 0;
-            return;
-        }
 #pragma unroll
         for (int half = 0; half < HALVES; ++half) {
             uint4 res[EPI == EPI_RESID ? SB : 1][EPI == EPI_RESID ? 4 : 1];
@@ -668,8 +628,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
                 const int n = n0 + wm * 128 + sp * 32 + (lane >> 4) * 8;
                 // bias from LDS (the whole vector was copied in at kernel start): no vector-memory load in the epilogue
                 // of the bias / GELU kernels, and no registers held across it
-                float4 bq[2] = {*reinterpret_cast<const float4*>(bias_lds + n), *reinterpret_cast<const float4*>(bias_lds + n + 4)};
-                if (p.pp_dbg & 8) bq[0] = bq[1] = float4{0.f, 0.f, 0.f, 0.f};
+                const float4 bq[2] = {*reinterpret_cast<const float4*>(bias_lds + n), *reinterpret_cast<const float4*>(bias_lds + n + 4)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
@@ -692,18 +651,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
                         w[2 * q] = pack_bf16x2(v0, v1);
                         w[2 * q + 1] = pack_bf16x2(v2, v3);
                     }
-                    // a plain store: hipcc may see it (the DMA pieces it must not see are asm); the same store through an asm
-                    // block (SQE_GEMM_DBG bit 256, knobs build) leaves garbage in the output -- cause not found
-                    if (p.pp_dbg & 256) store_b128_asm(reinterpret_cast<bf16_t*>(p.out) + o, uint4{w[0], w[1], w[2], w[3]});
-                    else if (!(p.pp_dbg & 2)) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) = uint4{w[0], w[1], w[2], w[3]};
+                    // a plain store: hipcc may see it (what it must not see are the DMA pieces).  The same 16-byte store
+                    // through an asm block left garbage in the output in r02 -- with s_nop padding for the store-data
+                    // hazard too; the 8-byte asm stores of the other GEMM kernels are fine -- cause not found, form not used.
+                    if (!(p.pp_dbg & 2)) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) = uint4{w[0], w[1], w[2], w[3]};
                 }
             }
         }
         post_epi = 2;
-        if (p.pp_dbg & 128) {                             // bisecting: drain instead of counting across the stores
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            post_epi = 0;
-        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
