@@ -622,13 +622,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
                     }
                 }
             }
+            // bias from LDS (the whole vector was copied in at kernel start): no vector-memory load in the epilogue of the
+            // bias / GELU kernels; all reads of a half up front, one LDS round trip (the operand registers are dead here)
+            float4 ball[SB][2];
+#pragma unroll
+            for (int ss = 0; ss < SB; ++ss) {
+                const int n = n0 + wm * 128 + (half * SB + ss) * 32 + (lane >> 4) * 8;
+                ball[ss][0] = *reinterpret_cast<const float4*>(bias_lds + n);
+                ball[ss][1] = *reinterpret_cast<const float4*>(bias_lds + n + 4);
+            }
 #pragma unroll
             for (int ss = 0; ss < SB; ++ss) {
                 const int sp = half * SB + ss;
                 const int n = n0 + wm * 128 + sp * 32 + (lane >> 4) * 8;
-                // bias from LDS (the whole vector was copied in at kernel start): no vector-memory load in the epilogue
-                // of the bias / GELU kernels, and no registers held across it
-                const float4 bq[2] = {*reinterpret_cast<const float4*>(bias_lds + n), *reinterpret_cast<const float4*>(bias_lds + n + 4)};
+                const float4 bq[2] = {ball[ss][0], ball[ss][1]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int tk = t0 + wn * 64 + j * 16 + (lane & 15);
