@@ -452,8 +452,8 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         {
             static const bool want = [] { const char* e = knob_env("SQE_DBG"); return e && (atoi(e) & 32); }();   // knobs build only
             if (want) {
-                SQE_TRY(idx->dbg.ensure(4096));
-                SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 4096, s));
+                SQE_TRY(idx->dbg.ensure(8192));
+                SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 8192, s));
                 a.dbg_counters = idx->dbg.as<unsigned long long>();
             }
         }
@@ -519,8 +519,8 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         c->unc_valid.store(true);
     }
     if (idx->dbg.p) {
-        unsigned long long h[512];
-        SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 4096, hipMemcpyDeviceToHost, s));
+        unsigned long long h[1024];
+        SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 8192, hipMemcpyDeviceToHost, s));
         SQE_HIP(hipStreamSynchronize(s));
         int wall_khz = 0;
         (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device);
@@ -543,6 +543,25 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
                             "mem of next tile %.0f + barrier %.0f, tile_end %.0f | %.2f general middle half-steps per tile at %.0f cycles each\n",
                     blk ? 100 : 0, o[0] / t, o[1] / t, o[2] / t, o[3] / t, o[4] / t, o[5] / t, o[6] / t, o[7] / t, o[8] / t, o[10] / t,
                     o[10] ? (double)o[9] / (double)o[10] : 0.0);
+        }
+        // drift between the workgroups that share a DB chunk (STAMPS build): spread of their arrival at two tiles
+        if (h[512] && plan.qblocks > 1 && plan.n_chunks * plan.qblocks <= 256) {
+            const int G = plan.n_chunks * plan.qblocks;
+            double worst[2] = {0, 0}, mean[2] = {0, 0};
+            for (int c = 0; c < plan.n_chunks; ++c)
+                for (int t = 0; t < 2; ++t) {
+                    unsigned long long lo = ~0ull, hi = 0;
+                    for (int qb = 0; qb < plan.qblocks; ++qb) {
+                        const int logical = c * plan.qblocks + qb;
+                        const int blk = (G & 7) == 0 ? (logical % (G >> 3)) * 8 + logical / (G >> 3) : logical;   // inverse of the kernel's remap
+                        const unsigned long long v = h[512 + blk * 2 + t];
+                        lo = std::min(lo, v); hi = std::max(hi, v);
+                    }
+                    const double d = (double)(hi - lo) / (wall_khz / 1e3);      // microseconds
+                    worst[t] = std::max(worst[t], d); mean[t] += d / plan.n_chunks;
+                }
+            fprintf(stderr, "[sqe dbg] spread between the %d workgroups of a chunk when they finish tile 100 / 400: mean %.1f / %.1f us, worst %.1f / %.1f us (one tile = ~30 us)\n",
+                    plan.qblocks, mean[0], mean[1], worst[0], worst[1]);
         }
         for (int blk = 0; blk < 2; ++blk)
             for (int w = 0; w < 8; ++w) {

@@ -42,6 +42,7 @@ struct ScanPlan {
     int ngroups;          // rows of the global-bound table per query slice (1: chunk c folds its maxima into column c % 64)
     int gshift;           // log2 group size of the global bound (64 >> gshift >= kp); -1 = off
     int gshift_k;         // log2 group size of the k-row bound (64 >> gshift_k >= k), used with the 2 eps slack; -1 = off
+    int k_rows;           // k when the k-row bound can take the k-th largest of the 16 group maxima (k <= 16), else 0
 };
 // k = 0: no k-row bound (the caller has no error bound for the scan scores)
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count, int k = 0);

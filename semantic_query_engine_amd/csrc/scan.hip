@@ -200,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
         // The fetch is younger than the DMA pieces of its own K step, so the counted wait that ends that
         // step leaves it in flight; the wait of the NEXT step retires it (NST = 2 drains everything every step).
         if (refresh_pending >= 0 && ++refresh_age >= (NST == 2 ? 1 : 2)) {
-            if (wave == (refresh_ctr & 7)) refresh_apply(f, gstage, refresh_pending, p.gshift, p.gshift_k, lane);
+            if (wave == (refresh_ctr & 7)) refresh_apply<BN == 256 ? 16 : GMAX_COLS>(f, gstage, refresh_pending, p.gshift, p.gshift_k, BN == 256 ? 0 : p.k_rows, lane);   // (256, the two-stage A/B form: no registers for 64 reads in flight or for the sort)
             refresh_pending = -1;
         }
         // prefetch stage s + NST - 1 (queries: s + NSTB - 1) into the buffer stage s - 1 used (its readers
@@ -322,6 +322,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
     k.ngroups = plan.ngroups; k.gshift = plan.gshift;
     k.q_resid = a.q_resid; k.db_resid_max = a.db_resid_max;
     k.gshift_k = (a.q_resid && a.db_resid_max) ? plan.gshift_k : -1;
+    k.k_rows = k.gshift_k == 2 ? plan.k_rows : 0;
     {
         static const int krot = [] { const char* e = knob_env("SQE_KROT"); return e ? atoi(e) : 0; }();
         static const int dbg = [] { const char* e = knob_env("SQE_DBG"); return e ? atoi(e) : 0; }();
@@ -355,7 +356,8 @@ ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count, int k) {
     // k-row bound (scan_common.h: refresh_apply): fewer, larger groups; pointless where it names the same groups
     p.gshift_k = k < 1 ? -1 : k <= 16 ? 2 : k <= 32 ? 1 : k <= 64 ? 0 : -1;
     if (p.gshift_k <= p.gshift) p.gshift_k = -1;
-    if (p.n_chunks < GMAX_COLS) p.gshift = p.gshift_k = -1;   // a column without a chunk: no cross-chunk bound
+    p.k_rows = (p.gshift_k == 2 && k <= 16) ? k : 0;
+    if (p.n_chunks < GMAX_COLS) { p.gshift = p.gshift_k = -1; p.k_rows = 0; }   // a column without a chunk: no cross-chunk bound
     return p;
 }
 

@@ -55,6 +55,7 @@ struct ScanKernelArgs {
     int ngroups;         // table rows per query slice (1: chunk c folds its maxima into column c % 64)
     int gshift;          // log2 of the group size g used by the global bound; < 0: bound off
     int gshift_k;        // log2 of the group size of the k-row bound (threshold = bound - slack); < 0: off
+    int k_rows;          // > 0 (then gshift_k == 2, k <= 16): the k-row bound is the k-th largest of the 16 quad maxima, not their minimum
     const float* q_resid;            // [B] error-bound inputs of the k-row bound (kernels.h: scan_eps)
     const uint32_t* db_resid_max;
     int krot;            // workgroup w walks K rotated by w * krot steps
@@ -422,23 +423,52 @@ __device__ __forceinline__ void refresh_issue(const uint32_t* gmax_block_group, 
 //     distinct rows reach, so their true cosines are >= L - eps, and a row whose scan score is below L - 2 eps
 //     has a true cosine below L - eps: it cannot be in the exact top-k.  Rows dropped under this bound need no
 //     certificate; with k = 10 of kp = 64 it sits well above the kp-row bound (fewer, larger groups beat the
-//     slack of ~0.16 sigma on 1024-d data), which is what makes tiles without any survivor the common case.
+//     slack of ~0.16 sigma on 1024-d data).  With k <= 16 the bound is sharper still: the k-th largest of the 16
+//     group maxima instead of their minimum (k_rows).
 // The query's threshold becomes the larger of the two (and of what it was).
-__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift, int gshift_k, int lane) {
+template <int READS_IN_FLIGHT = GMAX_COLS>
+__device__ __forceinline__ void refresh_apply(const Filter& f, const char* gstage, int sl, int gshift, int gshift_k, int k_rows, int lane) {
     const uint32_t* st = reinterpret_cast<const uint32_t*>(gstage) + lane;
     uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, b4 = 0xFFFFFFFFu;
-    // fully unrolled: all 64 reads are in flight together (ONE LDS round trip; four iterations per trip took four,
-    // and the other seven waves of the workgroup wait at the phase's barrier for this one)
-#pragma unroll
+    uint32_t qm[GMAX_COLS / 4];                     // the 16 quad maxima: 16 distinct rows of the index
+    // fully unrolled by default: all 64 reads are in flight together (ONE LDS round trip; four iterations per trip took
+    // four, and the other seven waves of the workgroup wait at the phase's barrier for this one).  READS_IN_FLIGHT = 16
+    // for the kernel that has no registers for that (the two-stage 256-query A/B form).
+    constexpr int UNROLL = READS_IN_FLIGHT / 4;
+#pragma unroll UNROLL
     for (int c = 0; c < GMAX_COLS; c += 4) {
         const uint32_t v0 = st[c * 64], v1 = st[(c + 1) * 64], v2 = st[(c + 2) * 64], v3 = st[(c + 3) * 64];
         const uint32_t p0 = max(v0, v1), p1 = max(v2, v3);
         b1 = min(b1, min(min(v0, v1), min(v2, v3)));
         b2 = min(b2, min(p0, p1));
-        b4 = min(b4, max(p0, p1));
+        qm[c >> 2] = max(p0, p1);
+        b4 = min(b4, qm[c >> 2]);
     }
     const uint32_t bound = gshift == 0 ? b1 : gshift == 1 ? b2 : gshift == 2 ? b4 : 0u;
-    const uint32_t lk = gshift_k == 0 ? b1 : gshift_k == 1 ? b2 : gshift_k == 2 ? b4 : 0u;
+    uint32_t lk = gshift_k == 0 ? b1 : gshift_k == 1 ? b2 : gshift_k == 2 ? b4 : 0u;
+    if (k_rows > 0) {
+        // k <= 16 of the 16 quad maxima suffice: the k-th LARGEST of them is a score k distinct rows reach -- the
+        // minimum is the 16th largest.  Batcher's odd-even merge sort on 16 registers (63 compare-exchanges), then
+        // the k-th by a chain of selects on the uniform k.  (Unpublished quads are 0 and sort to the bottom.)
+        constexpr int N = GMAX_COLS / 4;
+#pragma unroll
+        for (int pp = 1; pp < N; pp <<= 1)
+#pragma unroll
+            for (int kk = pp; kk >= 1; kk >>= 1)
+#pragma unroll
+                for (int j = kk % pp; j + kk < N; j += 2 * kk)
+#pragma unroll
+                    for (int i = 0; i < kk; ++i)
+                        if (i + j + kk < N && (i + j) / (2 * pp) == (i + j + kk) / (2 * pp)) {
+                            const uint32_t hi = max(qm[i + j], qm[i + j + kk]), lo = min(qm[i + j], qm[i + j + kk]);
+                            qm[i + j] = hi;                 // descending
+                            qm[i + j + kk] = lo;
+                        }
+        uint32_t kth = 0;
+#pragma unroll
+        for (int t = 0; t < N; ++t) kth = (k_rows == t + 1) ? qm[t] : kth;
+        lk = kth;
+    }
     const int q = sl * GSLICE_Q + lane;
     if (q < f.q_live) {
         uint32_t best = bound;                                   // 0 = some column not published yet / bound off

@@ -152,7 +152,7 @@ struct PP {
     int wave, wm, wn;
     int tile_begin, nt, HS, J;
     long long tile_bytes;
-    int kp, trig, gshift, gshift_k, refresh_mask;   // refresh_mask + 1: half-steps between bound fetches early in a chunk (power of two)
+    int kp, trig, gshift, gshift_k, k_rows, refresh_mask;   // refresh_mask + 1: half-steps between bound fetches early in a chunk (power of two)
     Cursor rd;                             // half-step the next MEM phase reads
     Cursor dm;                             // half-step the next MEM phase fetches (rd + 3)
     int refresh_pending, refresh_ctr, refresh_j;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     // ---- global bound: fold a slice fetched >= 3 half-steps ago (every wave's pieces have been
     // retired by its counted waits and a barrier), then maybe fetch the next one
     if (P.refresh_pending >= 0 && j >= P.refresh_j + 3) {
-        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.gshift_k, fresh_lane());
+        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.gshift_k, P.k_rows, fresh_lane());
         P.refresh_pending = -1;
     }
     // Schedule: entry 1 fetches all slices back to back from a quarter of the tile on
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     P.J = n_entries * P.HS;
     const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
     P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
-    P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift; P.gshift_k = p.gshift_k;
+    P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift; P.gshift_k = p.gshift_k; P.k_rows = p.k_rows;
     {
         int every = 1;
         while (every * 2 * NSLICEP <= P.HS) every *= 2;           // largest power of two <= HS / NSLICEP
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     P.no_mma = (SQE_DBG_BITS(p) & 1) != 0; P.no_dma = (SQE_DBG_BITS(p) & 2) != 0; P.no_filter = (SQE_DBG_BITS(p) & 4) != 0;
     if (SQE_DBG_BITS(p) & 8) P.gshift = P.gshift_k = -1;
     if (SQE_DBG_BITS(p) & 64) P.gshift_k = -1;          // kp-row bound only (the r01 filter)
+    if (SQE_DBG_BITS(p) & 2048) P.k_rows = 0;           // k-row bound from the minimum of the group maxima, not their k-th largest
     if (SQE_DBG_BITS(p) & 128) P.order = 0;             // every wave: pieces, then reads (the r01 order)
     if (SQE_DBG_BITS(p) & 256) P.order = 1;             // every wave: reads, then pieces
     if (SQE_DBG_BITS(p) & 512) P.order = P.wave & 1;    // stagger by wave parity instead of pairs
@@ -613,6 +614,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     PP_STAMP(b8);
                     ++j;
                     if (e + 1 < n_entries) tile_end(e);
+                    // drift of the query-block workgroups that share a chunk: constant-rate clock at two tiles, per workgroup
+                    PP_ACC(if (f.dbg_counters && tid == 0 && (e == 100 || e == 400)) f.dbg_counters[512 + blockIdx.x * 2 + (e == 400)] = wall_clock64());
                     PP_STAMP(b9);
                     PP_ACC(pclk.bnd[4] += b5 - b4; pclk.bnd[5] += b6 - b5; pclk.bnd[6] += b7 - b6; pclk.bnd[7] += b8 - b7; pclk.bnd[8] += b9 - b8);
                 }
@@ -659,6 +662,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     PP_BARRIER();
                     ++j;
                     if (e + 1 < n_entries) tile_end(e);
+                    // drift of the query-block workgroups that share a chunk: constant-rate clock at two tiles, per workgroup
+                    PP_ACC(if (f.dbg_counters && tid == 0 && (e == 100 || e == 400)) f.dbg_counters[512 + blockIdx.x * 2 + (e == 400)] = wall_clock64());
                 }
             }
 #ifdef SQE_PHASE_STAMPS
