@@ -153,6 +153,7 @@ struct PP {
     int tile_begin, nt, HS, J;
     long long tile_bytes;
     int kp, trig, gshift, gshift_k, k_rows, refresh_mask;   // refresh_mask + 1: half-steps between bound fetches early in a chunk (power of two)
+    int e_fast, e_mid, late_mask;          // bound-table fetch schedule (kernel start)
     Cursor rd;                             // half-step the next MEM phase reads
     Cursor dm;                             // half-step the next MEM phase fetches (rd + 3)
     int refresh_pending, refresh_ctr, refresh_j;
@@ -342,10 +343,10 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     // (when every chunk has published its boot maxima), then every slice once per tile while the
     // bound still moves fast, one slice per tile later.  At least 4 half-steps between fetches.
     if (P.bound_on && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && j >= P.refresh_j + 4) {
-        // ... and from tile 128 on -- the bound moves by 1 / t per tile by then -- one slice every second tile
+        // (schedule: e_fast / e_mid / late_mask, kernel start)
         const bool want = P.rd.e == 1 ? (P.rd.h >= P.HS / 4 && P.refresh_ctr < NSLICEP)
-                                      : (P.rd.e <= 32 ? (P.rd.h & P.refresh_mask) == 0
-                                                      : (P.rd.h == 0 && (P.rd.e <= 128 || (P.rd.e & 1) == 0)));
+                                      : (P.rd.e <= P.e_fast ? (P.rd.h & P.refresh_mask) == 0
+                                                            : (P.rd.h == 0 && (P.rd.e <= P.e_mid || (P.rd.e & P.late_mask) == 0)));
         if (want) {
             P.refresh_pending = P.refresh_ctr % NSLICEP;
             ++P.refresh_ctr;
@@ -368,7 +369,7 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     int next = j + 1;
     if (P.refresh_pending >= 0) next = max(j + 1, P.refresh_j + 3);           // the fetch in flight is folded then
     else if (P.rd.e >= 2) {
-        if (!P.bound_on || P.no_filter || P.rd.e > 32) next = P.J;               // next fetch: a tile's first half-step
+        if (!P.bound_on || P.no_filter || P.rd.e > P.e_fast) next = P.J;         // next fetch: a tile's first half-step
         else next = j + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask));
     }
     P.lean_until = P.no_dma ? 0 : min(next, P.J - 3);
@@ -445,6 +446,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     P.J = n_entries * P.HS;
     const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
     P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
+    {
+        // bound-table fetches: every slice per tile for the first e_fast tiles of a chunk, one slice per tile up to e_mid,
+        // then one slice every (late_mask + 1)-th tile.  A fetch costs ~2,500 cycles of the workgroup (16 KiB of DMA, two
+        // general phases, the fold in one wave) and the bound moves by 1 / t per tile: measured at 10 M rows, 32 / 128 / 2
+        // (r02a) against 4 / 32 / 4: batch 1024 17.31 -> 16.97 ms, 512 9.32 -> 9.09, 256 5.32 -> 5.17; 2 / 16 / 8 and
+        // 1 / 8 / 16 are no better.  SQE_DBG bit 4096 (knobs build): the r02a schedule.
+        const bool old_schedule = (SQE_DBG_BITS(p) & 4096) != 0;
+        P.e_fast = old_schedule ? 32 : 4;
+        P.e_mid = old_schedule ? 128 : 32;
+        P.late_mask = old_schedule ? 1 : 3;
+    }
     P.kp = p.kp; P.trig = p.trig; P.gshift = p.gshift; P.gshift_k = p.gshift_k; P.k_rows = p.k_rows;
     {
         int every = 1;
