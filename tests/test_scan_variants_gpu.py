@@ -63,10 +63,16 @@ def test_128_query_tile_ring_depths(ring, knobs_env):
     assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
 
 
-def test_kp_row_bound_alone(knobs_env):
-    """SQE_DBG=64 switches the k-row bound off (thresholds from the kp-row bound and the per-chunk lists only,
-    the r01 filter): a timing switch that must not change any answer."""
-    env = dict(knobs_env, SQE_DBG="64")
+@pytest.mark.parametrize("bits,what", [("64", "k-row bound off: thresholds from the kp-row bound and the per-chunk lists only (the r01 filter)"),
+                                       ("2048", "k-row bound from the minimum of the 16 group maxima instead of their k-th largest"),
+                                       ("4096", "bound table fetched on the r02a schedule (32 / 128 / every second tile)"),
+                                       ("128", "every wave issues its DMA pieces before its operand reads"),
+                                       ("1024", "all four DMA pieces of a half-step from the memory phase")],
+                         ids=["dbg64", "dbg2048", "dbg4096", "dbg128", "dbg1024"])
+def test_timing_switches_do_not_change_answers(bits, what, knobs_env):
+    """The SQE_DBG bits that select an older form of one mechanism (A/B timing in tools/ab_*.sh) must still return the
+    oracle's answer: they change when work happens, never what is computed."""
+    env = dict(knobs_env, SQE_DBG=bits)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "batch": 300}], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, what + "\n" + out.stderr[-2000:]
     assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
