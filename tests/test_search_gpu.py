@@ -267,13 +267,15 @@ def test_random_session_against_oracle(ctx):
     assert len(idx) == x.shape[0]
 
 
-@pytest.mark.parametrize("b,k", [(200, 16), (600, 10), (64, 16)])
+@pytest.mark.parametrize("b,k", [(200, 16), (600, 10), (64, 16), (300, 1), (300, 3), (300, 17), (300, 32), (300, 33)])
 def test_k_row_bound_keeps_rows_inside_the_error_band(ctx, b, k):
     """The scan drops rows below (a score k distinct rows reach) - 2 eps without a certificate (scan_common.h:
     refresh_apply).  Per query, 40 planted rows whose true cosines differ by 1e-5 -- far below the bf16 noise of
     the scan scores (~1e-4) -- so the bf16 order of the true top-k is scrambled and several of them score BELOW
     the k-row bound itself; only the 2 eps slack keeps them.  Enough rows for the cross-chunk bound to be active
-    (>= 64 chunks).  Ids and order must equal the float64 oracle."""
+    (>= 64 chunks).  Ids and order must equal the float64 oracle.  The k values cover every form of the bound: the
+    k-th largest of the 16 group maxima (k <= 16), the minimum over pairs of columns (17 .. 32), and none beside the
+    kp-row bound (33 and more)."""
     rng = np.random.default_rng(900 + b + k)
     d, n, planted = 256, 40000, 40
     x = rng.standard_normal((n, d)).astype(np.float32)
