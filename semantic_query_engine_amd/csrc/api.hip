@@ -544,6 +544,13 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
                     blk ? 100 : 0, o[0] / t, o[1] / t, o[2] / t, o[3] / t, o[4] / t, o[5] / t, o[6] / t, o[7] / t, o[8] / t, o[10] / t,
                     o[10] ? (double)o[9] / (double)o[10] : 0.0);
         }
+        for (int g = 0; g < 2; ++g) {
+            const unsigned long long* o = h + 300 + g * 8;
+            if (!o[4]) continue;
+            const double n = (double)o[4];
+            fprintf(stderr, "[sqe dbg] wg 0 group %d general memory phase x %llu: bookkeeping before %.0f, pieces + reads %.0f, wait %.0f, bookkeeping after %.0f\n",
+                    g, o[4], o[0] / n, o[1] / n, o[2] / n, o[3] / n);
+        }
         // drift between the workgroups that share a DB chunk (STAMPS build): spread of their arrival at two tiles
         if (h[512] && plan.qblocks > 1 && plan.n_chunks * plan.qblocks <= 256) {
             const int G = plan.n_chunks * plan.qblocks;

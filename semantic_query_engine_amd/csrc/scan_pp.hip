@@ -105,6 +105,17 @@ struct PhaseClock {
 #endif
 // stamps inside the memory phase lengthen it (each is an s_memtime the next use waits for): only with STAMPS=2
 #if defined(SQE_PHASE_STAMPS) && SQE_PHASE_STAMPS >= 2
+#define PP_DECL2(...) unsigned long long __VA_ARGS__
+#define PP_STAMP2(var) PP_STAMP(var)
+#else
+#define PP_DECL2(...) \
+    do {              \
+    } while (0)
+#define PP_STAMP2(var) \
+    do {               \
+    } while (0)
+#endif
+#if defined(SQE_PHASE_STAMPS) && SQE_PHASE_STAMPS >= 2
 #define PP_STAMP_MEM(var) PP_STAMP(var)
 #elif defined(SQE_PHASE_STAMPS)
 #define PP_STAMP_MEM(var) \
@@ -163,6 +174,9 @@ struct PP {
     int order;                             // how this wave lines up its DMA pieces and operand reads (dma_and_reads)
     int pend_h, pend_stage;                // query piece 1 of a half-step left for this wave's next compute phase (pend_h < 0: none)
     bool defer_on;
+#if defined(SQE_PHASE_STAMPS) && SQE_PHASE_STAMPS >= 2
+    unsigned long long mp[5] = {};         // general memory phase: bookkeeping before, pieces + reads, wait, bookkeeping after, count
+#endif
 
     __device__ __forceinline__ void advance(Cursor& c) const {
         if (++c.h == HS) {
@@ -331,6 +345,8 @@ __device__ __forceinline__ void dma_and_reads(const PP& P, AOps& a, BOps& b, int
 
 // MEMORY phase of half-step j (P.rd): bound work that is due, DMA of half-step j + 3, operand reads.
 __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps& b, int j) {
+    PP_DECL2(m0, m1, m2, m3, m4);
+    PP_STAMP2(m0);
     const bool more = j + 3 < P.J && !P.no_dma;
 
     // ---- global bound: fold a slice fetched >= 3 half-steps ago (every wave's pieces have been
@@ -356,26 +372,40 @@ __device__ __forceinline__ void mem_phase(PP& P, const Filter& f, AOps& a, BOps&
     }
 
     // ---- DMA of half-step j + 3 into the stage of half-step j - 1, operands of half-step j
+    PP_STAMP2(m1);
     dma_and_reads(P, a, b, j, more);
+    PP_STAMP2(m2);
 
     // ---- retire the DMA of half-step j + 1 (two MEM phases old); j + 2 and j + 3 stay in flight.
     // Anything else this wave issued in between (bound fetch, appended keys) only makes the wait
     // retire part of j + 2 as well.
     if (!more) PP_WAIT_VM0_LGKM0();
     else PP_WAIT_VM8_LGKM0();
+    PP_STAMP2(m3);
 
-    // ---- first half-step that needs this (general) form again; until then mem_lean runs.  (No division here: this
-    // bookkeeping runs in every general phase, and two integer modulos by a run-time value cost it ~450 cycles.)
-    int next = j + 1;
-    if (P.refresh_pending >= 0) next = max(j + 1, P.refresh_j + 3);           // the fetch in flight is folded then
-    else if (P.rd.e >= 2) {
-        if (!P.bound_on || P.no_filter || P.rd.e > P.e_fast) next = P.J;         // next fetch: a tile's first half-step
-        else next = j + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask));
+    // ---- first half-step that needs this (general) form again; until then EVERY memory phase takes the lean form
+    // (mem_any).  This function costs ~550 cycles of scalar bookkeeping beside its pieces and reads (SGPR state
+    // spilled to VGPR lanes, branches), so it runs at events only: a fold that is due, a fetch that is due.
+    // (j == rd.e * HS + rd.h: the half-step this phase handled.)
+    int next;
+    if (P.refresh_pending >= 0) next = max(j + 1, P.refresh_j + 3);                       // the fetch in flight is folded then
+    else if (!P.bound_on || P.no_filter) next = P.J;
+    else if (P.rd.e == 0) next = P.HS + P.HS / 4;                                         // entry 1, a quarter of the tile in
+    else if (P.rd.e == 1) next = P.refresh_ctr < NSLICEP ? max(max(j + 1, P.refresh_j + 4), P.HS + P.HS / 4) : 2 * P.HS;
+    else if (P.rd.e <= P.e_fast) next = max(j + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask)), P.refresh_j + 4);
+    else {                                                                                // first half-step of the next tile that fetches
+        int e2 = P.rd.e + 1;
+        if (e2 > P.e_mid) e2 = (e2 + P.late_mask) & ~P.late_mask;
+        next = e2 * P.HS;
     }
     P.lean_until = P.no_dma ? 0 : min(next, P.J - 3);
 
     P.advance(P.rd);
     P.advance(P.dm);
+#if defined(SQE_PHASE_STAMPS) && SQE_PHASE_STAMPS >= 2
+    PP_STAMP2(m4);
+    P.mp[0] += m1 - m0; P.mp[1] += m2 - m1; P.mp[2] += m3 - m2; P.mp[3] += m4 - m3; ++P.mp[4];
+#endif
 }
 
 // MEMORY phase without filter or bound work, j + 3 < J: the steady-state form.
@@ -409,6 +439,25 @@ __device__ __forceinline__ void mem_lean(PP& P, AOps& a, BOps& b, int j, bool de
     P.advance(P.rd);
     P.advance(P.dm);
 }
+
+#ifdef SQE_PHASE_STAMPS
+#define PP_MEM_ANY(j, defer_ok, pc) mem_any(P, f, a, b, j, defer_ok, pc)
+#else
+#define PP_MEM_ANY(j, defer_ok, pc) mem_any(P, f, a, b, j, defer_ok)
+#endif
+
+// memory phase of half-step j: the lean form unless an event is due (mem_phase sets P.lean_until <= J - 3)
+#ifdef SQE_PHASE_STAMPS
+__device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b, int j, bool defer_ok, PhaseClock& pc) {
+    if (j < P.lean_until) mem_lean(P, a, b, j, defer_ok && P.defer_on, pc);
+    else mem_phase(P, f, a, b, j);
+}
+#else
+__device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b, int j, bool defer_ok) {
+    if (j < P.lean_until) mem_lean(P, a, b, j, defer_ok && P.defer_on);
+    else mem_phase(P, f, a, b, j);
+}
+#endif
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -541,7 +590,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
             const int HS = P.HS;
             int j = 0;
 #ifdef SQE_PHASE_STAMPS
-            PhaseClock pclk;
+            PhaseClock pclk, scratch_clk;          // scratch_clk: phases outside the steady-state statistics
 #endif
             unsigned cols = 0;                 // column groups of the finished tile that hold a survivor
             int thr[4];
@@ -585,7 +634,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     PP_STAMP(b1);
                     PP_BARRIER();
                     PP_STAMP(b2);
-                    mem_phase(P, f, a, b, j + 1);
+                    PP_MEM_ANY(j + 1, HS > 2, scratch_clk);            // the next compute phase is a middle one unless HS == 2
                     if (HS == 2) load_thr();
                     PP_STAMP(b3);
                     PP_BARRIER();
@@ -620,7 +669,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     PP_STAMP(b5);
                     PP_BARRIER();
                     PP_STAMP(b6);
-                    if (e + 1 < n_entries) mem_phase(P, f, a, b, j + 1);
+                    if (e + 1 < n_entries) PP_MEM_ANY(j + 1, false, scratch_clk);
                     PP_STAMP(b7);
                     PP_BARRIER();
                     PP_STAMP(b8);
@@ -634,7 +683,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
             } else {
                 PP_BARRIER();
                 for (int e = 0; e < n_entries; ++e) {
-                    mem_phase(P, f, a, b, j);
+                    PP_MEM_ANY(j, false, scratch_clk);
                     PP_BARRIER();
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
                     PP_BARRIER();
@@ -686,6 +735,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 if (P.wave == 0)
                     for (int i = 0; i < 12; ++i) f.dbg_counters[8 + 128 + (blockIdx.x ? 16 : 0) + i] = pclk.bnd[i];
                 for (int i = 0; i < 6; ++i) f.dbg_counters[8 + 160 + (blockIdx.x ? 48 : 0) + P.wave * 6 + i] = pclk.te[i];
+#if SQE_PHASE_STAMPS >= 2
+                if (blockIdx.x == 0 && (P.wave == 0 || P.wave == 4))
+                    for (int i = 0; i < 5; ++i) f.dbg_counters[300 + (P.wave >> 2) * 8 + i] = P.mp[i];
+#endif
             }
 #endif
         }
