@@ -120,12 +120,13 @@ def cpu_baseline_hnsw(rows: int, b: int, k: int) -> dict:
     x = rng.standard_normal((rows, D), dtype=np.float32)
     q = rng.standard_normal((b, D), dtype=np.float32)
     q[: b // 2] = x[rng.integers(0, rows, b // 2)] + 0.1 * q[: b // 2]       # planted neighbours, as in the GPU run
-    # the GPU box hands a one-GPU job a share of its host CPUs (16): more threads than that only thrash
+    # every host core this process may run on (the GPU box hands a one-GPU job a share of its host CPUs); the build
+    # takes per-node locks, beyond 32 threads they only contend
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+    cores = max(1, min(cores, 32))
     t0 = time.perf_counter()
     h = HnswIndex(x, m=64, ef_construction=500, seed=0, threads=cores)
     build_s = time.perf_counter() - t0
@@ -265,7 +266,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
-    ap.add_argument("--cpu-hnsw-rows", type=int, default=20_000, help="rows of the CPU HNSW baseline (0 = skip)")
+    ap.add_argument("--cpu-hnsw-rows", type=int, default=50_000,
+                    help="rows of the CPU HNSW baseline (0 = skip; the build is superlinear on Gaussian rows: 50 k rows take "
+                         "~1 min on 8 cores, 200 k -- profiles/r03_search/hnsw_200k.json -- several minutes)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference timing")
     ap.add_argument("--force-collective", action="store_true",

@@ -383,8 +383,10 @@ namespace sqe {
 
 // The search pipeline on stream s (caller holds the index lock): query normalise -> bf16 scan with the fused
 // top-k filter -> select + fp32 rescore + certificate -> collect pass for uncertified queries.
+__global__ void add_count_kernel(int* acc, const int* v) { *acc += *v; }
+
 int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int nprobe, float* cos_out_dev, int64_t* id_out_dev,
-                      hipStream_t s) {
+                      hipStream_t s, int pass_index) {
     sqe_ctx* c = idx->ctx;
     if (idx->ivf) {
         StageTimer t(c->prof, s, ST_SCAN);
@@ -401,7 +403,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         for (int off = 0; off < B; off += MAX_PASS) {
             const int m = std::min(MAX_PASS, B - off);
             SQE_TRY(index_search_impl(idx, q_dev + (size_t)off * K, m, k, nprobe, cos_out_dev + (size_t)off * k,
-                                      id_out_dev + (size_t)off * k, s));
+                                      id_out_dev + (size_t)off * k, s, off / MAX_PASS));
         }
         return SQE_OK;
     }
@@ -415,7 +417,9 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
     SQE_TRY(idx->cand_cnt.ensure((size_t)plan.n_chunks * plan.b_pad * 4));
     const size_t gmax_bytes = (size_t)plan.b_pad * plan.ngroups * GMAX_COLS * 4;
     SQE_TRY(idx->gmax.ensure(gmax_bytes));
-    const bool certify = idx->certify && n_rows > 0;
+    // knobs build, timing experiments whose scan scores are wrong on purpose (SQE_DBG=8192): no certificate, no collect pass
+    static const bool no_collect = [] { const char* e = knob_env("SQE_NO_COLLECT"); return e && atoi(e) != 0; }();
+    const bool certify = idx->certify && n_rows > 0 && !no_collect;
     SQE_TRY(idx->q_resid.ensure((size_t)B * 4));
     if (certify) {
         SQE_TRY(idx->unc.ensure(16 + (size_t)plan.b_pad * 4));
@@ -514,8 +518,10 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             e.cos_out = cos_out_dev; e.id_out = id_out_dev; e.id_base = idx->id_base;
             SQE_TRY(launch_collect_rescore(e, s));
         }
-        // the count goes to a buffer the CONTEXT owns (sqe_stats reads it long after this index may be gone)
-        SQE_HIP(hipMemcpyAsync(c->unc_last.p, unc_count, 4, hipMemcpyDeviceToDevice, s));
+        // the count goes to a buffer the CONTEXT owns (sqe_stats reads it long after this index may be gone); the
+        // passes of a batch above MAX_PASS add up (r02: the last pass's count overwrote the others)
+        if (pass_index == 0) SQE_HIP(hipMemcpyAsync(c->unc_last.p, unc_count, 4, hipMemcpyDeviceToDevice, s));
+        else hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, s, c->unc_last.as<int>(), unc_count);
         c->unc_valid.store(true);
     }
     if (idx->dbg.p) {
@@ -927,42 +933,78 @@ int sqe_set_profiling(sqe_ctx* ctx, int on) {
     return SQE_OK;
 }
 
+// one context's share of the statistics, ADDED to *out (timings, calls, uncertified queries of its last search)
+static int stats_accumulate(sqe_ctx* ctx, sqe_stats_t* out) {
+    SQE_HIP(hipSetDevice(ctx->device));
+    ctx->prof.drain();
+    {
+        std::lock_guard<std::mutex> lk(ctx->prof.mu);
+        out->scan_ms += ctx->prof.ms[ST_SCAN] + ctx->prof.ms[ST_COLLECT];   // collect-pass scans are scans
+        out->prep_ms += ctx->prof.ms[ST_PREP];
+        out->select_ms += ctx->prof.ms[ST_SELECT];
+        out->add_ms += ctx->prof.ms[ST_ADD];
+        out->encode_ms += ctx->prof.ms[ST_ENCODE];
+        out->cache_ms += ctx->prof.ms[ST_CACHE];
+        out->scan_calls += ctx->prof.calls[ST_SCAN];
+    }
+    if (ctx->unc_valid.load()) {
+        // the count was written on the stream of that search; a device-wide wait orders this read after it
+        // whatever stream it was (stats are not on any hot path)
+        int v = 0;
+        SQE_HIP(hipDeviceSynchronize());
+        if (hipMemcpy(&v, ctx->unc_last.p, 4, hipMemcpyDeviceToHost) == hipSuccess) out->uncertified += v;
+    }
+    return SQE_OK;
+}
+
 int sqe_stats(sqe_ctx* ctx, sqe_stats_t* out) {
     if (!ctx) return fail(SQE_ERR_INVALID, "null handle");
     if (!out) return fail(SQE_ERR_INVALID, "sqe_stats: out is null");
-    SQE_HIP(hipSetDevice(ctx->device));
-    ctx->prof.drain();
     memset(out, 0, sizeof(*out));
-    {
-        std::lock_guard<std::mutex> lk(ctx->prof.mu);
-        out->scan_ms = ctx->prof.ms[ST_SCAN] + ctx->prof.ms[ST_COLLECT];   // collect-pass scans are scans
-        out->prep_ms = ctx->prof.ms[ST_PREP];
-        out->select_ms = ctx->prof.ms[ST_SELECT];
-        out->add_ms = ctx->prof.ms[ST_ADD];
-        out->encode_ms = ctx->prof.ms[ST_ENCODE];
-        out->cache_ms = ctx->prof.ms[ST_CACHE];
-        out->scan_calls = ctx->prof.calls[ST_SCAN];
+    SQE_TRY(stats_accumulate(ctx, out));
+    // A multi-device context: the shards of its indexes belong to the member contexts, which is where their
+    // searches book timings and uncertified counts (r02: the leader reported shard 0 only).  Timings add up over
+    // the members (device time, not wall time: the shards run side by side), so does the uncertified count (a query
+    // can fail its certificate on one shard and pass on another: the sum counts collect passes, not queries).
+    if (ctx->group) {
+        const int n = group_member_count(ctx);
+        for (int p = 1; p < n; ++p) SQE_TRY(stats_accumulate(group_member(ctx, p), out));
+        SQE_HIP(hipSetDevice(ctx->device));
+        out->scan_rows = 0; out->scan_flops = 0; out->scan_bytes = 0;
+        for (int p = 0; p < n; ++p) {
+            sqe_ctx* m = group_member(ctx, p);
+            out->scan_rows += m->last_scan_rows.load();
+            out->scan_flops += m->last_scan_flops.load();
+            out->scan_bytes += m->last_scan_bytes.load();
+        }
+        out->search_calls = ctx->search_calls.load();
+        return SQE_OK;
     }
     out->search_calls = ctx->search_calls.load();
     out->scan_rows = ctx->last_scan_rows.load();
     out->scan_flops = ctx->last_scan_flops.load();
     out->scan_bytes = ctx->last_scan_bytes.load();
-    if (ctx->unc_valid.load()) {
-        // the copy into unc_last was enqueued on the stream of that search; a device-wide wait orders this
-        // read after it whatever stream it was (stats are not on any hot path)
-        int v = 0;
-        SQE_HIP(hipDeviceSynchronize());
-        if (hipMemcpy(&v, ctx->unc_last.p, 4, hipMemcpyDeviceToHost) == hipSuccess) out->uncertified = v;
-    }
     return SQE_OK;
 }
 
-int sqe_stats_reset(sqe_ctx* ctx) {
-    if (!ctx) return fail(SQE_ERR_INVALID, "null handle");
+static void stats_reset_one(sqe_ctx* ctx) {
     ctx->prof.drain();
     std::lock_guard<std::mutex> lk(ctx->prof.mu);
     for (int i = 0; i < ST_COUNT; ++i) { ctx->prof.ms[i] = 0; ctx->prof.calls[i] = 0; }
     ctx->search_calls.store(0);
+}
+
+int sqe_stats_reset(sqe_ctx* ctx) {
+    if (!ctx) return fail(SQE_ERR_INVALID, "null handle");
+    stats_reset_one(ctx);
+    if (ctx->group) {
+        for (int p = 1; p < group_member_count(ctx); ++p) {
+            sqe_ctx* m = group_member(ctx, p);
+            (void)hipSetDevice(m->device);
+            stats_reset_one(m);
+        }
+        (void)hipSetDevice(ctx->device);
+    }
     return SQE_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <string>
 #include <utility>
 
+#include "host_errors.h"
 #include "sqe.h"
 
 namespace sqe {
@@ -42,9 +43,7 @@ inline const char* knob_env(const char* name) {
 #endif
 }
 
-// ---------------------------------------------------------------- error plumbing
-void set_error(const std::string& msg);
-int fail(int code, const std::string& msg);
+// ---------------------------------------------------------------- error plumbing (set_error, fail: host_errors.h)
 
 #define SQE_HIP(expr)                                                                   \
     do {                                                                                \

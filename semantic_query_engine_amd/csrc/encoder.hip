@@ -249,6 +249,12 @@ int launch_gemm_cfg(const GemmArgs& a, int t_pad, hipStream_t stream) {
 // them in flight.  Stores and DMA pieces go through inline asm so that hipcc inserts no vmcnt(0) of its
 // own.  Consecutive tile ids share the token tile or the weight tile, so the 256 tiles in flight at any
 // time reuse each other's operands in L2.
+// Hazard audit (r03, DESIGN.md "asm stores"): the data of this store always comes out of v_cvt_pk_bf16_f32 -- a VALU
+// write, which the hardware interlocks against a VMEM read of the same VGPR (no software wait states; the MFMA ->
+// VALU distance in front of the pack is hipcc's, both instructions being visible to it) -- and a store of at most
+// 8 bytes has read its data by the time the next instruction issues.  The 16-byte form does NOT have that second
+// property (its data registers must not be written for two wait states AFTER it): r02 padded in front of it instead
+// and got garbage; the large-batch epilogue's 16-byte stores are plain stores hipcc pads itself.
 __device__ __forceinline__ void store_b64_asm(void* p, uint2 v) {
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     u32x2 w;

@@ -193,6 +193,9 @@ void group_destroy(sqe_ctx* leader) {
     delete g;
 }
 
+int group_member_count(const sqe_ctx* leader) { return leader->group ? (int)leader->group->members.size() : 1; }
+sqe_ctx* group_member(sqe_ctx* leader, int p) { return leader->group ? leader->group->members[p] : leader; }
+
 int group_describe(sqe_ctx* leader, int* n_shards, int* exchange, int* device_ids, int cap) {
     Group* g = leader->group;
     if (n_shards) *n_shards = g->P;

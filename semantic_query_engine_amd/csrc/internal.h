@@ -237,7 +237,7 @@ int index_grow(sqe_index* idx, int64_t need_rows, hipStream_t s);
 int index_add_impl(sqe_index* idx, const float* x_dev, int64_t n, int64_t x_stride, bool restore, hipStream_t s);
 int index_update_impl(sqe_index* idx, const int64_t* rows_dev, const float* x_dev, int64_t n, hipStream_t s);
 int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int nprobe, float* cos_out_dev, int64_t* id_out_dev,
-                      hipStream_t s);
+                      hipStream_t s, int pass_index = 0);
 
 // ---- IVF layer (ivf.hip); every call runs under the base index's lock, on stream s
 int ivf_create(sqe_index* base, IvfState** out);
@@ -267,5 +267,7 @@ int group_index_set_option(sqe_index* idx, const char* key, double value);
 int group_index_search(sqe_index* idx, const float* q, int B, int k, int nprobe, float* cos_out, int64_t* id_out, bool on_device);
 int group_index_save_rows(sqe_index* idx, FILE* f, void* pinned, size_t pinned_bytes);
 int group_describe(sqe_ctx* leader, int* n_shards, int* exchange, int* device_ids, int cap);
+int group_member_count(const sqe_ctx* leader);          // shards of the context (1 without a group)
+sqe_ctx* group_member(sqe_ctx* leader, int p);          // member context p (0 = the leader itself)
 
 }  // namespace sqe

@@ -314,9 +314,24 @@ constexpr int LS_ROWS = 256, LS_Q = 64, LS_NST = 3, LS_SEG = 4096;
 constexpr int LS_STAGE = (LS_ROWS + LS_Q) * 128;
 constexpr int LS_LDS = LS_NST * LS_STAGE + LS_SEG * 4 + LS_Q * 4;
 
+// Stores through inline asm: a store hipcc knows about would make it guard the ring's invisible DMA pieces with
+// vmcnt(0).  hipcc pads no hazard whose producer or consumer sits inside an asm string, so the two software wait-state
+// rules that touch this store are met INSIDE it ("asm stores"):
+//   (a) XDL (MFMA) write of a VGPR -> VMEM read of it as store data: 11 wait states behind an 8-pass MFMA
+//       (v_mfma_f32_16x16x32_bf16) -- mfma_results_to_vmem() below, once per epilogue, tied to the accumulators;
+//   (b) a VMEM store of more than 8 bytes reads its data registers up to two wait states after it issued: nothing
+//       may write them before -- the s_nop 1 that ends the string (a nop in FRONT of the store, r02's encoder attempt,
+//       covers nothing: the next v_cvt_pk_bf16_f32 overwrote the registers of the store just issued).
 __device__ __forceinline__ void global_store_f4_asm(float* p, f32x4 v) {
-    // inline asm: a store hipcc knows about would make it guard the ring's invisible DMA pieces with vmcnt(0)
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// 12 wait states between the MFMAs that produced `acc` and whatever follows (the "+v" operands keep those MFMAs above)
+template <int N, int M>
+__device__ __forceinline__ void mfma_results_to_vmem(f32x4 (&acc)[N][M]) {
+    static_assert(N == 2 && M == 4, "the list-scan tile: 2 x 4 fragments per wave");
+    asm volatile("s_nop 11"
+                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                   "+v"(acc[1][2]), "+v"(acc[1][3]));
 }
 
 __global__ __launch_bounds__(512) void ivf_list_scan_mfma_kernel(const bf16_t* __restrict__ scan, int pitch,
@@ -414,6 +429,7 @@ __global__ __launch_bounds__(512) void ivf_list_scan_mfma_kernel(const bf16_t* _
                 }
                 if (++ks == KS) {
                     // scores of this tile: a lane holds 4 consecutive rows of one query per fragment
+                    mfma_results_to_vmem(acc);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int col = j * 16 + (lane & 15);

@@ -48,10 +48,15 @@ struct ScanPlan {
 ScanPlan make_scan_plan(int64_t n_rows, int B, int kp, int cu_count, int k = 0);
 
 // Upper bound of |bf16 scan score - fp32 cosine| for a query with bf16 residual norm dq over rows whose residual
-// norms are at most dx:  |<q_b, x_b> - <q, x>| <= ||q_b|| ||x - x_b|| + ||q - q_b|| ||x||, plus the difference of
-// the two fp32 accumulation orders.  ONE definition: the scan's k-row bound and the certificate must agree on it.
-__host__ __device__ inline float scan_eps(float dq, float dx) {
-    return (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + 2.0e-4f;
+// norms are at most dx:  |<q_b, x_b> - <q, x>| <= ||q_b|| ||x - x_b|| + ||q - q_b|| ||x||, plus the rounding of the
+// two fp32 accumulations that are compared (the scan's MFMA chain and the re-score's FMA chain): each is within
+// K * 2^-24 * sum |a_i b_i| <= K * 2^-24 of the exact dot product of its unit-norm operands, together K * 2^-23.
+// The term is floored at 2e-4 (its r01/r02 value, which covers K <= 1677): at dim 1024 nothing changes, and the
+// proof holds for every dim sqe_index_create admits (r02 kept the constant while admitting dim 8192, where the worst
+// case is 9.8e-4).  ONE definition: the scan's k-row bound and the certificate must agree on it.
+__host__ __device__ inline float scan_eps(float dq, float dx, int K) {
+    const float acc = fmaxf(2.0e-4f, (float)K * 1.1920929e-7f * 1.05f);
+    return (1.0f + dq) * dx * 1.000001f + dq * 1.000001f + acc;
 }
 
 struct ScanArgs {

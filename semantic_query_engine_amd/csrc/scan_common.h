@@ -503,7 +503,7 @@ __device__ __forceinline__ void filter_init(const ScanKernelArgs& p, const Filte
         f.thr_s[i] = ts;
         f.cnt[i] = 0;
         f.cmax[i] = 0u;
-        slack[i] = (live && p.gshift_k >= 0 && p.q_resid) ? 2.0f * scan_eps(p.q_resid[q0 + i], dx) * 1.000001f + 1.0e-6f : INFINITY;
+        slack[i] = (live && p.gshift_k >= 0 && p.q_resid) ? 2.0f * scan_eps(p.q_resid[q0 + i], dx, p.K) * 1.000001f + 1.0e-6f : INFINITY;
     }
     if (tid < 16) f.flags[tid] = 0;
 }

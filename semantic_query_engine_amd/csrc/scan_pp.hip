@@ -161,6 +161,8 @@ struct PP {
     unsigned offA0, offA1, offB0, offB1;   // per-lane source offsets of this wave's DMA pieces
     unsigned rdA, rdB;                     // per-lane LDS offsets of the operand reads inside a stage
     int wave, wm, wn;
+    bool tile_skew;                        // knobs build, SQE_DBG bit 8192: tiles start (tile % 16) * 2 KiB into their footprint
+    int h_stride;                          // bytes between the 32-wide K slices of a DB tile row (64; knobs build: see SQE_DBG bit 8192)
     int tile_begin, nt, HS, J;
     long long tile_bytes;
     int kp, trig, gshift, gshift_k, k_rows, refresh_mask;   // refresh_mask + 1: half-steps between bound fetches early in a chunk (power of two)
@@ -191,7 +193,10 @@ struct PP {
     // this wave's four 1-KiB pieces of a half-step: DB pieces wave, wave + 8; query pieces likewise
     __device__ __forceinline__ void issue_a(const Cursor& c, int stage) const {
         char* st = smem + stage * STAGE_BYTES;
-        const char* as = c.tile + c.h * (HALF_K * 2);
+        const char* as = c.tile + c.h * h_stride;
+        // (emulated tiled layout: a row-major tile's footprint is 17 x 32 KiB, so without a skew the half-step blocks of
+        // all chunks would sit at the same address modulo 32 KiB -- the same channels and L2 sets)
+        if (tile_skew) as += (((c.e < nt ? c.e : 0) + tile_begin) & 15) * 2048;
         glds16(as + offA0, st + wave * 1024);
         glds16(as + offA1, st + (wave + 8) * 1024);
     }
@@ -553,6 +558,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
         P.offB0 = (unsigned)(row * ldB) + (c & 3) * 16;
         P.offA1 = P.offA0 + (unsigned)(64 * ldA);      // piece wave + 8: 64 lines further, same swizzle
         P.offB1 = P.offB0 + (unsigned)(64 * ldB);
+        P.h_stride = HALF_K * 2;
+        // Timing experiment (knobs build, WRONG scores): read the DB tile as if it were stored K-slice-major
+        // ([half-step][256 rows][64 B]: every half-step takes 16 KiB of whole 128-B lines, each fetched once per workgroup)
+        // -- what a tiled scan copy would cost in time and L2 fills, before anything is rebuilt around it.
+        if (SQE_DBG_BITS(p) & 8192) {
+            P.offA0 = (unsigned)(row * 64) + (c & 3) * 16;
+            P.offA1 = P.offA0 + 64 * 64;
+            P.h_stride = SCAN_BM * 64;
+        }
+        P.tile_skew = (SQE_DBG_BITS(p) & 8192) != 0;
     }
     // ---- per-lane operand read offsets: fragment fm / fn adds fm * 2048 (16 lines)
     {
@@ -572,6 +587,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     f32x4 acc[8][4];
     AOps a;
     BOps b;
+    // Timing experiment (knobs build): static priority for the second-dispatched half of the workgroup
+    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
+    if ((SQE_DBG_BITS(p) & 16384) && group == 1) __builtin_amdgcn_s_setprio(1);
+    if ((SQE_DBG_BITS(p) & 32768) && group == 0) __builtin_amdgcn_s_setprio(1);
 
     // ---- prologue: half-steps 0, 1, 2 (J >= 4 whenever J > 0: boot + rescan entries, K >= 64)
     if (P.J > 0) {

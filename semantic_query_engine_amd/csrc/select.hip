@@ -198,7 +198,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore_kernel(SelectKerne
             float thr = INFINITY;                    // certified: nothing to collect
             const float unseen = fmaxf(T != 0ull ? key_score(T) : -INFINITY, gfin);
             if (unseen > -INFINITY) {
-                const float eps = scan_eps(p.q_resid[q], __uint_as_float(*p.db_resid_max));
+                const float eps = scan_eps(p.q_resid[q], __uint_as_float(*p.db_resid_max), p.K);
                 const bool certified = m >= p.k && kth_score > unseen + eps;
                 if (!certified) {
                     atomicAdd(p.unc_count, 1);

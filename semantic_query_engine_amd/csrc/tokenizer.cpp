@@ -12,12 +12,14 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
-#include "common.h"
+#include "host_errors.h"
 #include "unicode_tables.h"
 
 struct sqe_tokenizer {

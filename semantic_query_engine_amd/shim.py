@@ -40,6 +40,7 @@ from fastapi import FastAPI, Request, Response
 from fastapi.responses import JSONResponse
 
 _SHARDS = {"total": 1, "successful": 1, "skipped": 0, "failed": 0}
+MAX_SEARCH_K = 256                                       # sqe_index_search: 1 <= k <= 256 (include/sqe.h)
 
 
 class _EmbedBatcher:
@@ -127,10 +128,24 @@ class _SearchBatcher:
                     for g, h in zip(group, hits):
                         if not g[4].done():
                             g[4].set_result(h)
-                except Exception as e:                    # every waiter of this index sees the failure
+                except Exception as e:
+                    # A failing batch must not turn every co-batched client's search into a 500 (requests are
+                    # validated before they are queued, so this is a device error or a request the validation
+                    # missed): run the group's requests one by one, only the offending ones fail.
+                    if len(group) == 1:
+                        if not group[0][4].done():
+                            group[0][4].set_exception(e)
+                        continue
                     for g in group:
-                        if not g[4].done():
-                            g[4].set_exception(e)
+                        if g[4].done():
+                            continue
+                        try:
+                            h = await loop.run_in_executor(None, _search_hits_batch, self.client, name, g[1], [g[2]], [g[3]])
+                            self.batches += 1
+                            self.batch_sizes.append(1)
+                            g[4].set_result(h[0])
+                        except Exception as e1:
+                            g[4].set_exception(e1)
 
 
 def _os_error(status: int, etype: str, reason: str, **extra) -> JSONResponse:
@@ -269,13 +284,20 @@ def create_app(client, embedder=None, embed_dim: int = 1024) -> FastAPI:
             body = json.loads(raw) if raw.strip() else {}
             knn = body["query"]["knn"]
             (field, spec), = knn.items()
-            vector = np.asarray(spec["vector"], dtype=np.float32)[None, :]
+            vector = np.asarray(spec["vector"], dtype=np.float32)
             k = int(body.get("size", spec.get("k", 10)))
             k = max(1, min(k, int(spec.get("k", k)))) if "k" in spec else k
         except (KeyError, ValueError, TypeError) as e:
             return _os_error(400, "parsing_exception", f"only {{'query': {{'knn': {{field: {{'vector', 'k'}}}}}}}} is served: {e}")
-        if vector.shape[1] != client.dim:
-            return _os_error(400, "illegal_argument_exception", f"query vector has {vector.shape[1]} dimensions, index has {client.dim}")
+        # every request is validated BEFORE it joins a batch: one malformed request must fail alone
+        if vector.ndim != 1 or vector.shape[0] != client.dim:
+            got = "x".join(str(d) for d in vector.shape) or "a scalar"
+            return _os_error(400, "illegal_argument_exception", f"query vector must be a flat list of {client.dim} numbers, got {got}")
+        if not np.all(np.isfinite(vector)):
+            return _os_error(400, "illegal_argument_exception", "query vector holds a NaN or an infinity")
+        if not 1 <= k <= MAX_SEARCH_K:
+            return _os_error(400, "illegal_argument_exception", f"size / k must be in [1, {MAX_SEARCH_K}] (sqe_index_search), got {k}")
+        vector = vector[None, :]
         try:
             hits = await searcher.search(index, vector, k, field)
         except Exception as e:

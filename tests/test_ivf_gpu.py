@@ -58,3 +58,36 @@ def test_ivf_matches_oracle_and_recall(ctx, nlist):
     idx.update(np.array([5]), q[:1] * 3.0)
     cos, ids = idx.search(q[:1], 1, nprobe=4)
     assert ids[0, 0] == 5 and abs(cos[0, 0] - 1.0) < 1e-5
+
+
+def test_ivf_strip_budget_sub_batches(ctx):
+    """r01 advisor / r02 verdict: the score strips are [queries, nprobe, longest list] floats and are capped at 6 GiB
+    (ivf.hip: STRIP_BUDGET); a batch over the cap runs as sub-batches, each a complete search of its queries.  One
+    list holding > 30 % of 600 k rows (a duplicate-heavy index: 60 distinct vectors, ~3,400 copies each, all in the
+    list of one centroid) at nprobe 16 makes a strip of ~13 MB per query, so a batch of 1,000 queries cannot run in
+    one piece (~480 fit): the result must equal the oracle's IVF search on the exported structure for EVERY query --
+    the ones of the later sub-batches and the ones whose neighbours are copies inside the long list included."""
+    from semantic_query_engine_amd import INDEX_IVF_FLAT, VectorIndex
+    n, d, k, nlist, nprobe, b = 600_000, 64, 5, 64, 16, 1000
+    rng = np.random.default_rng(41)
+    cen = rng.standard_normal((64, d)).astype(np.float32)
+    x = (cen[rng.integers(0, 64, n)] + 0.3 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    light_sample = x[rng.permutation(n)[:60000]].copy()                  # the training sample: before the copies go in
+    heavy = rng.permutation(n)[: int(0.34 * n)]
+    distinct = (cen[7][None, :] + 0.3 * rng.standard_normal((60, d), dtype=np.float32)).astype(np.float32)
+    x[heavy] = distinct[rng.integers(0, 60, heavy.size)]
+    q = (x[rng.integers(0, n, b)] + 0.2 * rng.standard_normal((b, d), dtype=np.float32)).astype(np.float32)
+    idx = VectorIndex(ctx, d, INDEX_IVF_FLAT, nlist)
+    idx.train(light_sample, iters=6, seed=5)
+    idx.add(x)
+    centroids, assign = idx.ivf_export(nlist)
+    longest = int(np.bincount(assign, minlength=nlist).max())
+    assert longest >= 0.30 * n, longest
+    assert nprobe * ((longest + 3) // 4 * 4) * 4 * b > 6 << 30          # one piece would not fit the budget
+    cos, ids = idx.search(q, k, nprobe=nprobe)
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    ref_cos, ref_ids = R.ivf_search(xn, qn, centroids, assign, k, nprobe)
+    # copies have identical cosines: any of them is a right answer (assert_topk_matches accepts an id whose true score
+    # equals the expected one), ids inside a row stay distinct
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
+    idx.close() if hasattr(idx, "close") else None

@@ -237,6 +237,83 @@ def test_concurrent_searches_share_one_batched_scan():
         assert hits[0]["_source"]["text"] == f"chunk {want[0][0]}"
 
 
+def _small_oracle_index(n=200, seed=5, vectors_cls=None):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, DIM)).astype(np.float32)
+    oc = OracleClient(DIM)
+    named = oc.index("idx")
+    if vectors_cls is not None:
+        named.vectors = vectors_cls(DIM)
+    named.vectors.add(x)
+    named.sources = [{"doc_id": f"PMC{i}.txt", "text": f"chunk {i}"} for i in range(n)]
+    named.row_of_id = {f"PMC{i}.txt_{i}": i for i in range(n)}
+    return oc, named, x
+
+
+def test_malformed_search_requests_fail_alone():
+    """r02 advisor finding: a request is validated before it joins a batch -- a nested vector, a wrong length, a
+    non-finite value or k outside [1, 256] answers 400 by itself, and the good requests sent at the same moment
+    still get their oracle answers from one batched call."""
+    oc, named, x = _small_oracle_index()
+    good = [float(v) for v in x[7]]
+    bad_bodies = [
+        {"size": 3, "query": {"knn": {"embedding": {"vector": [good, good], "k": 3}}}},           # (2, dim): nested
+        {"size": 3, "query": {"knn": {"embedding": {"vector": [[v] for v in good], "k": 3}}}},    # (dim, 1): passed r02's shape check
+        {"size": 3, "query": {"knn": {"embedding": {"vector": good[:-1], "k": 3}}}},
+        {"size": 1000, "query": {"knn": {"embedding": {"vector": good, "k": 1000}}}},             # k > 256
+        {"size": 3, "query": {"knn": {"embedding": {"vector": 1.5, "k": 3}}}},
+    ]
+
+    async def many():
+        app = shim.create_app(oc, None, DIM)
+        app.state.search_batcher.max_wait = 0.3
+        import httpx
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://shim") as ac:
+            reqs = [ac.post("/idx/_search", json=b) for b in bad_bodies]
+            reqs += [ac.post("/idx/_search", json={"size": 3, "query": {"knn": {"embedding": {"vector": [float(v) for v in x[i]], "k": 3}}}})
+                     for i in (7, 11, 13)]
+            # NaN cannot travel as JSON through httpx's encoder: send the body by hand
+            nan_body = json.dumps({"size": 3, "query": {"knn": {"embedding": {"vector": good, "k": 3}}}}).replace(repr(good[0]), "NaN", 1)
+            reqs.append(ac.post("/idx/_search", content=nan_body, headers={"content-type": "application/json"}))
+            return await asyncio.gather(*reqs), app.state.search_batcher
+    rs, sb = asyncio.run(many())
+    for r in rs[:len(bad_bodies)]:
+        assert r.status_code == 400, r.text
+    assert rs[-1].status_code == 400
+    for r, i in zip(rs[len(bad_bodies):-1], (7, 11, 13)):
+        assert r.status_code == 200
+        assert r.json()["hits"]["hits"][0]["_id"] == f"PMC{i}.txt_{i}"
+    assert sb.batches == 1 and sb.batch_sizes == [3]                     # the bad requests never reached the batcher
+
+
+def test_device_failure_in_a_batch_fails_only_the_offending_request():
+    """If a batched call does fail, the group's requests are re-run one by one: only the request that cannot be
+    served answers 500 (r02: every co-batched client saw the failure)."""
+    class Picky(OracleVectors):
+        def search(self, q, k, nprobe=0):
+            q = np.asarray(q)
+            if np.any(np.abs(q[:, 0] - 12345.0) < 0.5):                  # the poisoned query fails whatever batch it is in
+                raise RuntimeError("sqe_index_search: hip error")
+            return super().search(q, k, nprobe)
+
+    oc, named, x = _small_oracle_index(vectors_cls=Picky)
+    poisoned = x[3].copy()
+    poisoned[0] = 12345.0
+
+    async def many():
+        app = shim.create_app(oc, None, DIM)
+        app.state.search_batcher.max_wait = 0.3
+        import httpx
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://shim") as ac:
+            vecs = [x[5], poisoned, x[9]]
+            return await asyncio.gather(*[ac.post("/idx/_search", json={"size": 2, "query": {"knn": {"embedding": {
+                "vector": [float(v) for v in q], "k": 2}}}}) for q in vecs]), app.state.search_batcher
+    rs, sb = asyncio.run(many())
+    assert [r.status_code for r in rs] == [200, 500, 200]
+    assert rs[0].json()["hits"]["hits"][0]["_id"] == "PMC5.txt_5" and rs[2].json()["hits"]["hits"][0]["_id"] == "PMC9.txt_9"
+    assert "hip error" in rs[1].json()["error"]["reason"]
+
+
 def test_failed_device_add_keeps_docstore_and_vectors_in_step():
     """A bulk request whose device add fails must not leave documents behind: later adds still land at
     vector row == docstore row, and hits map to the right documents."""

@@ -66,6 +66,31 @@ __global__ __launch_bounds__(512) void k32(const bf16x8* __restrict__ src, float
     }
 }
 
+// int8: 8 x 4 fragments of 16x16x64 per wave and trip: 32 MFMAs of 16*16*64*2 = 32768 op -> 1048576 op per trip
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__global__ __launch_bounds__(512) void k16i8(const i32x4* __restrict__ src, float* __restrict__ out, int trips) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    i32x4 a[8], b[4];
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < 8; ++i) a[i] = src[(i * 64 + lane) & 4095];
+    for (int i = 0; i < 4; ++i) b[i] = src[((8 + i) * 64 + lane) & 4095];
+    i32x4 acc[8][4] = {};
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    int s = 0;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 123456789) out[0] = (float)s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<long long*>(out)[1] = clock64() - c0;
+        reinterpret_cast<long long*>(out)[2] = wall_clock64() - w0;
+    }
+}
+
 static uint16_t bf16_of(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
 
 int main(int argc, char** argv) {
@@ -109,5 +134,40 @@ int main(int argc, char** argv) {
                    ticks[2] ? (double)ticks[1] / ticks[2] * wall_khz / 1e3 : 0.0);
             fflush(stdout);
         }
+    // int8 MFMA (v_mfma_i32_16x16x64_i8) on zeros / on Gaussian rows quantised at 4.5 sigma = 127 (sigma = 28 LSB)
+    {
+        std::vector<int8_t> hb(4096 * 16);
+        const char* names[3] = {"zeros", "gauss int8 (sigma 28)", "gauss int8, 2 waves/SIMD"};
+        for (int data = 0; data < 3; ++data) {
+            srand(7);
+            for (auto& v : hb) {
+                float g = 0.f;
+                if (data) { for (int i = 0; i < 12; ++i) g += rand() / (float)RAND_MAX; g = (g - 6.f) * 28.f; }
+                int q = (int)lrintf(g); q = q > 127 ? 127 : q < -127 ? -127 : q;
+                v = (int8_t)q;
+            }
+            CK(hipMemcpy(src, hb.data(), hb.size(), hipMemcpyHostToDevice));
+            const int threads = data == 2 ? 512 : 256;
+            const int grid = cus;
+            double best = 0, last = 0;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                k16i8<<<grid, threads>>>(reinterpret_cast<const i32x4*>(src), out, trips);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                const double op = (double)grid * (threads / 64) * trips * 1048576.0;
+                last = op / (ms * 1e-3) / 1e12;
+                if (last > best) best = last;
+            }
+            long long ticks[3];
+            CK(hipMemcpy(ticks, out, 24, hipMemcpyDeviceToHost));
+            int wall_khz = 0;
+            CK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
+            printf("{\"shape\": \"i8 16x16x64\", \"data\": \"%s\", \"cus\": %d, \"waves_per_simd\": %d, \"tops_last\": %.1f, \"tops_best\": %.1f, "
+                   "\"clock64_mhz\": %.0f}\n", names[data], cus, threads / 256, last, best,
+                   ticks[2] ? (double)ticks[1] / ticks[2] * wall_khz / 1e3 : 0.0);
+            fflush(stdout);
+        }
+    }
     return 0;
 }
