@@ -36,6 +36,7 @@ import torch
 D = 1024
 BLOCK_ROWS = 1 << 20          # DB is generated in blocks of 1M rows, seed = base + block
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_I8_TOPS = 5000.0         # dense int8 MFMA: twice the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores table)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -264,6 +265,8 @@ def main():
                          "N x as large (e.g. 10000000 -> 80M rows on 8 GPUs); overrides --rows")
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--scan-mode", choices=["bf16", "int8"], default="bf16",
+                    help="first-pass scan type (sqe.h: SQE_SCAN_*); both return the exact fp32 top-k behind a certificate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--cpu-hnsw-rows", type=int, default=50_000,
@@ -324,6 +327,10 @@ def main():
         del x, xs
     assert len(idx) == row_hi - row_lo
     torch.cuda.empty_cache()
+    int8 = args.scan_mode == "int8"
+    if int8:
+        from semantic_query_engine_amd import SCAN_INT8_RESCORE
+        idx.set_option("scan_mode", SCAN_INT8_RESCORE)
 
     q = make_queries(b, device)
     # plant true neighbours for half the queries so recall is non-trivial
@@ -395,19 +402,21 @@ def main():
         tflops = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
         gbps = bytes_ / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         # binding roof: the scan needs max(flops/peak_mfma, bytes/peak_hbm) at best
-        t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), bytes_ / (PEAK_HBM_GBPS * 1e9)
+        used_i8 = int8 and st.get("i8_collected", 0) > 0
+        peak_mfma = PEAK_I8_TOPS if used_i8 else PEAK_BF16_TFLOPS
+        t_mfma, t_hbm = flops / (peak_mfma * 1e12), bytes_ / (PEAK_HBM_GBPS * 1e9)
         if t_mfma >= t_hbm:
-            roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": None}
+            roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak_mfma, "unit": "TOP/s" if used_i8 else "TFLOP/s",
+                    "frac": round(tflops / peak_mfma, 4), "traffic": None}
         else:
             roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None}
-        roof.update({"kernel": "scan_bf16_pp_kernel" if b > 128 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
+        roof.update({"kernel": "scan_i8_pp_kernel" if used_i8 else "scan_bf16_pp_kernel" if b > 128 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                      "hbm_gbps": round(gbps, 1), "mfma_tflops": round(tflops, 2)})
-        if world == 1:
+        if world == 1 and not used_i8:
             roof["traffic"], roof["traffic_source"] = committed_traffic(n_total, b)
-        if roof["bound"] == "mfma" and world == 1 and not args.no_gemm_ref:
+        if roof["bound"] == "mfma" and world == 1 and not args.no_gemm_ref and not used_i8:
             lib = library_gemm_tflops(b, device)
             roof["library_gemm_tflops"] = round(lib, 1)
             roof["frac_of_library_gemm"] = round(tflops / lib, 4)
@@ -417,14 +426,17 @@ def main():
                       f"k-NN queries/sec (brute-force cosine top-{k}, 1024-d, {n_total} vectors)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if args.rows_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"flat cosine top-{k}, N={n_total} x {D} fp32 (bf16 scan + fp32 rescore), "
+            "scaling": "weak" if args.rows_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "i8" if used_i8 else "bf16", "data": "synthetic",
+            "config": {"workload": f"flat cosine top-{k}, N={n_total} x {D} fp32 ({'int8 collect scan' if used_i8 else 'bf16 scan'} + fp32 rescore, certified exact), "
                                    f"batch={b} queries/step, index row-sharded over {world} GPU(s)",
                        "rows": n_total, "dim": D, "batch": b, "k": k, "parallelism": f"shard{world}"},
             "recall_at_10": round(recall, 4), "max_abs_dcos": max_dcos, "planted_top1_ok": planted_ok,
             "uncertified_queries_last_step": int(st.get("uncertified", 0)),
             "stage_ms": {"prep": round(st["prep_ms"] / args.steps, 4), "scan": round(scan_ms, 4),
-                         "select_rescore": round(st["select_ms"] / args.steps, 4)},
+                         "select_rescore": round(st["select_ms"] / args.steps, 4),
+                         **({"threshold_pass": round(st["sample_ms"] / args.steps, 4)} if used_i8 else {})},
+            **({"int8_last_step": {"keys_collected": int(st["i8_collected"]), "rows_rescored": int(st["i8_rescored"]),
+                                   "overflows": int(st["i8_overflows"])}} if used_i8 else {}),
             "roofline": roof,
         }
         if args.force_collective:

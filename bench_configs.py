@@ -96,6 +96,43 @@ def build_random_index(ctx, rows, dev, kind=0, nlist=0, clustered=None):
     return idx
 
 
+def cpu_encoder_baseline(cases, max_seconds: float = 40.0) -> dict:
+    """CPU baseline of the encoder leg: torch CPU `BertModel` with the
+    BERT-large configuration and seeded random weights (fp32, no pooler), all host cores this process may use, for each
+    (batch, seq_len) in `cases` -- (1, 512) is what Ollama does per request (main.py:134-145: one text per call).
+    A reported baseline, timed AFTER the GPU measurements; bounded: one warm-up + as many passes as fit in
+    `max_seconds` per case (at least one)."""
+    import transformers
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, cores))
+    cfg = transformers.BertConfig(vocab_size=BERT_LARGE["vocab_size"], hidden_size=1024, num_hidden_layers=24,
+                                  num_attention_heads=16, intermediate_size=4096, max_position_embeddings=512,
+                                  type_vocab_size=2, hidden_act="gelu", layer_norm_eps=1e-12)
+    torch.manual_seed(0)
+    model = transformers.BertModel(cfg, add_pooling_layer=False).eval()
+    out = {"kind": "port", "cores": int(cores), "model": "transformers.BertModel, BERT-large config, random fp32 weights, torch CPU",
+           "cases": []}
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for b, sl in cases:
+            ids = torch.randint(1000, BERT_LARGE["vocab_size"], (b, sl), generator=g)
+            t0 = time.perf_counter()
+            model(input_ids=ids)                                  # warm-up (allocations, thread pool)
+            first = time.perf_counter() - t0
+            n, t0 = 0, time.perf_counter()
+            while n == 0 or (time.perf_counter() - t0 + first < max_seconds and n < 5):
+                model(input_ids=ids)
+                n += 1
+            sec = (time.perf_counter() - t0) / n
+            out["cases"].append({"batch": b, "seq_len": sl, "ms": round(sec * 1e3, 1), "tokens_per_s": round(b * sl / sec),
+                                 "texts_per_s": round(b / sec, 2), "tflops": round(encoder_flops(b * sl, sl) / sec / 1e12, 3),
+                                 "passes": n})
+    return out
+
+
 def mode_e2e(args, ctx, dev):
     from semantic_query_engine_amd.encoder import BertEncoder
     enc = BertEncoder(ctx)
@@ -121,6 +158,9 @@ def mode_e2e(args, ctx, dev):
                              "roofline_search": {"bound": "hbm", "achieved": round(sbytes / srch_ms / 1e6, 1), "peak": 8000.0,
                                                  "unit": "GB/s", "frac": round(sbytes / srch_ms / 1e6 / 8000.0, 4), "traffic": None,
                                                  "algorithmic_bytes": sbytes}})
+    if not args.no_cpu_baseline:
+        del idx
+        out["cpu_baseline"] = cpu_encoder_baseline([(1, 32), (64, 32), (1, 512)])
     print(json.dumps(out), flush=True)
 
 
@@ -136,9 +176,12 @@ def mode_encode(args, ctx, dev):
     torch.cuda.synchronize()
     ms = timed(lambda: enc.encode_ids_device(ids.data_ptr(), lens.data_ptr(), b, s, emb.data_ptr()), ctx.synchronize, 3, 1)
     flops = encoder_flops(b * s, s)
-    print(json.dumps({"mode": "encode", "batch": b, "seq_len": s, "ms": round(ms, 2), "tokens_per_s": round(b * s / ms * 1e3),
-                      "chunks_per_s": round(b / ms * 1e3, 1), "mfma_tflops": round(flops / ms / 1e9, 1),
-                      "frac_of_bf16_peak": round(flops / ms / 1e9 / 2500.0, 4), "roofline": mfma_roofline(flops, ms)}), flush=True)
+    res = {"mode": "encode", "batch": b, "seq_len": s, "ms": round(ms, 2), "tokens_per_s": round(b * s / ms * 1e3),
+           "chunks_per_s": round(b / ms * 1e3, 1), "mfma_tflops": round(flops / ms / 1e9, 1),
+           "frac_of_bf16_peak": round(flops / ms / 1e9 / 2500.0, 4), "roofline": mfma_roofline(flops, ms)}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_encoder_baseline([(1, 512), (b, 512)])
+    print(json.dumps(res), flush=True)
 
 
 def build_clustered(ctx, rows, dev, centres, kind, nlist, keep_host=None):
@@ -221,10 +264,30 @@ def mode_ivf(args, ctx, dev):
     cf = torch.empty((b, k), device=dev); jf = torch.empty((b, k), dtype=torch.int64, device=dev)
     flat_ms = timed(lambda: flat.search_device(q.data_ptr(), b, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
     ivf_bytes = args.rows * D * 2                          # every list is probed at B = 1024: one read of the scan copy
+    # ---- batch sweep (r02 verdict: the reference issues B = 1, main.py:355): IVF and flat at 1 / 8 / 64 / 256 / 1024 of the
+    # same queries.  Algorithmic bytes of a point: the rows of the DISTINCT lists its queries probe (from the exported
+    # assignment and the oracle's probe order on the exported centroids) x D x 2.
+    sweep = []
+    cen64 = centroids.astype(np.float64)
+    list_len = np.bincount(assign, minlength=nlist)
+    qn_all = R.normalize_rows(q.cpu().numpy()).astype(np.float64)
+    for bb in (1, 8, 64, 256, 1024):
+        if bb > b:
+            break
+        t_ivf = timed(lambda: ivf.search_device(q.data_ptr(), bb, k, ci.data_ptr(), ji.data_ptr(), nprobe=nprobe), ctx.synchronize, 10)
+        t_flat = timed(lambda: flat.search_device(q.data_ptr(), bb, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
+        probes = np.argsort(-(qn_all[:bb] @ cen64.T), axis=1, kind="stable")[:, :nprobe]
+        rows_touched = int(list_len[np.unique(probes)].sum())
+        by = rows_touched * D * 2
+        sweep.append({"batch": bb, "ivf_ms": round(t_ivf, 4), "ivf_qps": round(bb / t_ivf * 1e3), "flat_ms": round(t_flat, 4),
+                      "flat_qps": round(bb / t_flat * 1e3), "rows_in_probed_lists": rows_touched,
+                      "roofline": {"bound": "hbm", "achieved": round(by / t_ivf / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(by / t_ivf / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes": by}})
     print(json.dumps({"mode": "ivf", "rows": args.rows, "nlist": nlist, "nprobe": nprobe, "batch": b, "train_s": round(train_s, 2),
                       "flat_ms": round(flat_ms, 3), "flat_qps": round(b / flat_ms * 1e3), "ivf_ms": round(ivf_ms, 3),
                       "ivf_qps": round(b / ivf_ms * 1e3), "probe_queries": int(probe.numel()),
                       "parity_vs_oracle_ivf": round(parity, 4), "recall_at_10_vs_exact": round(recall_exact, 4),
+                      "batch_sweep": sweep,
                       "roofline": {"bound": "hbm", "achieved": round(ivf_bytes / ivf_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                    "frac": round(ivf_bytes / ivf_ms / 1e6 / 8000.0, 4), "traffic": None,
                                    "algorithmic_bytes": ivf_bytes}}), flush=True)
@@ -321,6 +384,7 @@ def main():
     ap.add_argument("--mode", required=True, choices=["e2e", "ivf", "encode", "cache", "hard", "ingest"])
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="encode / e2e: skip the torch CPU BertModel baseline")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)

@@ -53,11 +53,19 @@ enum {
 
 enum { SQE_INDEX_FLAT = 0, SQE_INDEX_IVF_FLAT = 1 };
 
-/* How the stored rows are scanned.  Both return exact fp32 cosines of the returned ids.
- *   BF16_RESCORE: bf16 MFMA scan keeps the best `rescore_k` per query, which are then
- *                 re-scored in fp32 from the fp32 master copy (default);
- *   FP32:         fp32 MFMA scan of the master copy (exact ordering by construction). */
-enum { SQE_SCAN_BF16_RESCORE = 0, SQE_SCAN_FP32 = 1 };
+/* How the stored rows are scanned.  Both return the exact fp32 top-k: cosines are fp32 re-scores from the fp32
+ * master copy, and a per-query certificate (option "certify") proves that no row outside the re-scored set can
+ * reach the k-th cosine -- the rounding of every scanned copy is measured and bounded -- with a bf16 collect pass
+ * for the queries where the proof fails.
+ *   BF16_RESCORE: bf16 MFMA scan with a fused top-k filter (default; every batch size, every index size);
+ *   INT8_RESCORE: int8 MFMA first pass at twice the bf16 rate over a per-row-scaled int8 copy (+1 byte per element):
+ *                 a 2 % row sample fixes per-query thresholds, the int8 scan collects every row above them, the
+ *                 collected rows are re-scored in fp32.  Used for batches > 128 on FLAT indexes of >= "i8_min_rows"
+ *                 rows (default 1 M), dim >= 256, k <= 32; everything else runs the bf16 scan.  Suited to rows whose
+ *                 elements are of similar magnitude (unit Gaussian-like embeddings): the int8 error bound is ~8 x the
+ *                 bf16 one, and data on which it is too wide simply takes the bf16 pass.
+ * (r02's header also listed an fp32 scan mode that was never built; it is gone.) */
+enum { SQE_SCAN_BF16_RESCORE = 0, SQE_SCAN_INT8_RESCORE = 2 };
 
 /* ---- library / context ---------------------------------------------------------- */
 int sqe_version(void);
@@ -70,7 +78,9 @@ const char* sqe_last_error(void);
  * exchanges the packed [B,k] results in ONE step -- RCCL all-gather over xGMI (ncclCommInitAll, one
  * communicator per device) or, where RCCL is unavailable, peer copies to device_ids[0] -- before the merge
  * on device_ids[0].  Device pointers of "_device" entry points are memory of device_ids[0].  Caches and
- * encoders live on device_ids[0] (replicas only); IVF indexes are single-device. */
+ * encoders live on device_ids[0] (replicas only).  IVF indexes shard the same way: sqe_index_train
+ * runs k-means once on device_ids[0] and replicates the centroids, every device keeps the lists of the rows it owns,
+ * all devices probe the same lists and the per-device top-k go through the same exchange + merge. */
 int sqe_create(const int* device_ids, int n_dev, sqe_ctx** out);
 /* General form: `exchange` picks the exchange step, and device ids may repeat (several logical shards on
  * one device -- how a one-GPU box rehearses the sharded path; those use the copy exchange).  A group of ONE
@@ -108,7 +118,8 @@ int sqe_index_count(const sqe_index* idx, int64_t* out);
 /* Normalised fp32 rows as stored (`_source.embedding` of a hit, main.py:327-331). */
 int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, float* out_host);
 
-/* Options: "scan_mode" (SQE_SCAN_*), "rescore_k" (candidates kept by the bf16 scan,
+/* Options: "scan_mode" (SQE_SCAN_*; int8 tuning: "i8_min_rows", "i8_sample_step" = sample every n-th tile,
+ * "i8_sample_m" = the threshold is the m-th best cosine of the sample), "rescore_k" (candidates kept by the bf16 scan,
  * 0 = automatic), "nprobe" default for IVF, "id_base" (added to every returned row id:
  * the first global row of this shard in a row-sharded index), "certify" (default 1: prove
  * per query that no row outside the re-scored candidates can reach the k-th cosine -- the
@@ -226,6 +237,10 @@ typedef struct sqe_stats_t {
     int64_t scan_flops;    /* 2 * rows * dim * B of the last search */
     int64_t scan_bytes;    /* algorithmic bytes of the last search */
     int64_t uncertified;   /* queries of the last search that needed the exact fp32 rescan */
+    double sample_ms;      /* int8 mode: threshold pass (bf16 scan + re-score of the row sample) */
+    int64_t i8_collected;  /* int8 mode, last search: keys the collect scan appended (all queries) */
+    int64_t i8_rescored;   /*   rows re-scored in fp32 */
+    int64_t i8_overflows;  /*   queries whose lists or buffers overflowed (they took the bf16 pass) */
 } sqe_stats_t;
 int sqe_set_profiling(sqe_ctx* ctx, int on);
 int sqe_stats(sqe_ctx* ctx, sqe_stats_t* out);

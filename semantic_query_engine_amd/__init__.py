@@ -8,7 +8,7 @@ reference interface (``retrieval``).  There is no CPU fallback: importing ``_nat
 fails loudly when the library has not been built.
 """
 from .engine import (EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL, INDEX_FLAT, INDEX_IVF_FLAT, SCAN_BF16_RESCORE,
-                     SCAN_FP32, CacheMatrix, Context, VectorIndex)
+                     SCAN_INT8_RESCORE, CacheMatrix, Context, VectorIndex)
 
 __all__ = ["Context", "VectorIndex", "CacheMatrix", "INDEX_FLAT", "INDEX_IVF_FLAT",
-           "SCAN_BF16_RESCORE", "SCAN_FP32", "EXCHANGE_AUTO", "EXCHANGE_RCCL", "EXCHANGE_COPY"]
+           "SCAN_BF16_RESCORE", "SCAN_INT8_RESCORE", "EXCHANGE_AUTO", "EXCHANGE_RCCL", "EXCHANGE_COPY"]

@@ -27,7 +27,9 @@ class Stats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("prep_ms", C.c_double), ("select_ms", C.c_double),
                 ("add_ms", C.c_double), ("encode_ms", C.c_double), ("cache_ms", C.c_double),
                 ("scan_calls", C.c_int64), ("search_calls", C.c_int64), ("scan_rows", C.c_int64),
-                ("scan_flops", C.c_int64), ("scan_bytes", C.c_int64), ("uncertified", C.c_int64)]
+                ("scan_flops", C.c_int64), ("scan_bytes", C.c_int64), ("uncertified", C.c_int64),
+                ("sample_ms", C.c_double), ("i8_collected", C.c_int64), ("i8_rescored", C.c_int64),
+                ("i8_overflows", C.c_int64)]
 
 
 # name -> (restype, argtypes): every symbol include/sqe.h declares

@@ -105,6 +105,11 @@ int index_update_impl(sqe_index* idx, const int64_t* rows_dev, const float* x_de
     SQE_TRY(launch_normalize_rows_scatter(x_dev, rows_dev, n, idx->dim, idx->master, idx->scan, idx->pitch / 2,
                                           idx->resid_max.as<uint32_t>(), s));
     if (idx->ivf) SQE_TRY(ivf_rows_updated(idx, idx->ivf, rows_dev, n, s));   // only the overwritten rows are re-assigned
+    // the int8 copy follows (rows past i8_rows are quantised again by the next search; the residual maximum only grows)
+    if (idx->i8db.p && idx->i8_cap_tiles == idx->cap / SCAN_BM)
+        SQE_TRY(launch_quantize_rows_i8(idx->master, rows_dev, 0, n, idx->dim, idx->i8db.as<int8_t>(), idx->i8_tile_stride,
+                                        idx->i8sxi.as<uint32_t>(), idx->i8resid_max.as<uint32_t>(), s));
+    else idx->i8_rows = 0;      // the index grew since the copy was made: the next search rebuilds it from the master, whole
     return SQE_OK;
 }
 
@@ -166,6 +171,8 @@ static int ctx_init_device(sqe_ctx* c, int device) {
     SQE_TRY(c->host.init());
     SQE_TRY(c->unc_last.ensure(16));
     SQE_HIP(hipMemsetAsync(c->unc_last.p, 0, 16, c->own_stream));
+    SQE_TRY(c->i8_last.ensure(32));
+    SQE_HIP(hipMemsetAsync(c->i8_last.p, 0, 32, c->own_stream));
     return SQE_OK;
 }
 
@@ -358,9 +365,19 @@ int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
     std::lock_guard<std::mutex> lk(idx->ord.mu);
     const std::string k(key);
     if (k == "scan_mode") {
-        if ((int)value != SQE_SCAN_BF16_RESCORE)
-            return fail(SQE_ERR_UNSUPPORTED, "scan_mode: only SQE_SCAN_BF16_RESCORE is implemented in this build");
+        if ((int)value != SQE_SCAN_BF16_RESCORE && (int)value != SQE_SCAN_INT8_RESCORE) return fail(SQE_ERR_INVALID, "scan_mode: unknown mode");
+        if ((int)value == SQE_SCAN_INT8_RESCORE && idx->kind != SQE_INDEX_FLAT)
+            return fail(SQE_ERR_INVALID, "scan_mode: the int8 first pass is for FLAT indexes");
         idx->scan_mode = (int)value;
+    } else if (k == "i8_min_rows") {
+        if (value < 0) return fail(SQE_ERR_INVALID, "i8_min_rows must be >= 0");
+        idx->i8_min_rows = (int64_t)value;
+    } else if (k == "i8_sample_step") {
+        if (value < 1 || value > 4096) return fail(SQE_ERR_INVALID, "i8_sample_step must be in [1, 4096]");
+        idx->i8_sample_step = (int)value;
+    } else if (k == "i8_sample_m") {
+        if (value < 1 || value > 64) return fail(SQE_ERR_INVALID, "i8_sample_m must be in [1, 64]");
+        idx->i8_sample_m = (int)value;
     } else if (k == "rescore_k") {
         if (value < 0 || value > MAX_KP) return fail(SQE_ERR_INVALID, "rescore_k must be in [0, 256]");
         idx->rescore_k = (int)value;
@@ -383,7 +400,101 @@ namespace sqe {
 
 // The search pipeline on stream s (caller holds the index lock): query normalise -> bf16 scan with the fused
 // top-k filter -> select + fp32 rescore + certificate -> collect pass for uncertified queries.
+// The int8 copy of the stored rows (scan_mode INT8) is derived data, filled lazily: the first search after an add
+// quantises rows [i8_rows, n) from the fp32 master (one streaming pass, ~5 KiB per row).  Tiles are independent, so a
+// grown index keeps what it has.
+static int ensure_i8_copy(sqe_index* idx, hipStream_t s) {
+    const int K = idx->dim;
+    const int64_t n_rows = idx->n.load();
+    const int64_t cap_tiles = idx->cap / SCAN_BM;
+    const int64_t stride = (int64_t)(K / 64) * 16384 + 2048;     // + 2 KiB: chunk streams do not start at the same address modulo 256 KiB
+    if (idx->i8_cap_tiles != cap_tiles || idx->i8_tile_stride != stride) {
+        DevBuf nd, ns;
+        SQE_TRY(nd.ensure((size_t)cap_tiles * stride));
+        SQE_TRY(ns.ensure((size_t)cap_tiles * SCAN_BM * 4));
+        SQE_HIP(hipMemsetAsync(nd.p, 0, nd.bytes, s));            // rows past n read as zero vectors
+        SQE_HIP(hipMemsetAsync(ns.p, 0, ns.bytes, s));
+        if (idx->i8_rows > 0 && idx->i8_tile_stride == stride) {
+            const int64_t tiles = (idx->i8_rows + SCAN_BM - 1) / SCAN_BM;
+            SQE_HIP(hipMemcpyAsync(nd.p, idx->i8db.p, (size_t)tiles * stride, hipMemcpyDeviceToDevice, s));
+            SQE_HIP(hipMemcpyAsync(ns.p, idx->i8sxi.p, (size_t)tiles * SCAN_BM * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            idx->i8_rows = 0;
+        }
+        SQE_HIP(hipStreamSynchronize(s));                         // the old buffers die here
+        std::swap(nd.p, idx->i8db.p); std::swap(nd.bytes, idx->i8db.bytes);
+        std::swap(ns.p, idx->i8sxi.p); std::swap(ns.bytes, idx->i8sxi.bytes);
+        idx->i8_cap_tiles = cap_tiles;
+        idx->i8_tile_stride = stride;
+    }
+    if (!idx->i8resid_max.p) {
+        SQE_TRY(idx->i8resid_max.ensure(16));
+        SQE_HIP(hipMemsetAsync(idx->i8resid_max.p, 0, 16, s));
+    }
+    if (idx->i8_rows < n_rows) {
+        StageTimer t(idx->ctx->prof, s, ST_ADD);
+        SQE_TRY(launch_quantize_rows_i8(idx->master, nullptr, idx->i8_rows, n_rows - idx->i8_rows, K, idx->i8db.as<int8_t>(), stride,
+                                        idx->i8sxi.as<uint32_t>(), idx->i8resid_max.as<uint32_t>(), s));
+        idx->i8_rows = n_rows;
+    }
+    return SQE_OK;
+}
+
 __global__ void add_count_kernel(int* acc, const int* v) { *acc += *v; }
+
+// Second pass for the queries whose certificate failed (bf16 or int8 first pass alike): they are compacted into a
+// dense batch on the device, a bf16 collect scan gathers every row whose scan score can still reach the query's k-th
+// cosine (collect_thr[q] = that cosine - bf16 eps, +inf for certified queries) and the gathered rows are re-scored in fp32.
+static int run_collect_fallback(sqe_index* idx, int B, int k, int kp, int b_pad, int* unc_count, float* collect_thr,
+                                float* cos_out_dev, int64_t* id_out_dev, int pass_index, hipStream_t s) {
+    sqe_ctx* c = idx->ctx;
+    const int K = idx->dim;
+    const int64_t n_rows = idx->n.load();
+    {
+        StageTimer t(c->prof, s, ST_SELECT);
+        SQE_TRY(launch_compact_uncertified(collect_thr, B, idx->qb.as<bf16_t>(), idx->pitch, K * 2, idx->unc_ids.as<int>(),
+                                           idx->thr_c.as<float>(), b_pad + 256, idx->qb_c.as<bf16_t>(), unc_count, s));
+    }
+        {
+            // The collect scans are scans: they are booked under scan_ms (scan_calls counts the main launches
+            // only).  One launch per range of counts is enqueued, each planned like a search of that batch size
+            // and returning at once unless the count is in its range (and at once when it is 0).
+            StageTimer t(c->prof, s, ST_COLLECT);
+            ScanArgs a;
+            a.db = idx->scan; a.q = idx->qb_c.as<bf16_t>(); a.n_rows = n_rows; a.K = K; a.B = B;
+            a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
+            a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
+            a.dbg_counters = nullptr;
+            a.q_resid = nullptr; a.db_resid_max = nullptr;
+            a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
+            a.unc_count = unc_count;
+            const int bounds[5] = {0, 64, 256, 512, 1 << 30};
+            for (int r = 0; r < 4 && bounds[r] < B; ++r) {
+                const int hi = std::min(bounds[r + 1], B);
+                const ScanPlan cp = make_scan_plan(n_rows, hi, kp, c->cu_count);
+                a.collect_lo = bounds[r] + 1;
+                a.collect_hi = r == 3 ? (1 << 30) : bounds[r + 1];
+                SQE_TRY(launch_scan_collect(cp, a, s));
+            }
+        }
+        {
+            // ... and re-score them in fp32
+            StageTimer t(c->prof, s, ST_SELECT);
+            ExactArgs e;
+            e.master = idx->master; e.qn = idx->qn.as<float>(); e.K = K; e.B = B; e.k = k;
+            e.collect_thr = collect_thr; e.keys = idx->fb_keys.as<uint64_t>(); e.key_cnt = idx->fb_cnt.as<int>();
+            e.unc_ids = idx->unc_ids.as<int>(); e.unc_count = unc_count;
+            e.cos_out = cos_out_dev; e.id_out = id_out_dev; e.id_base = idx->id_base;
+            SQE_TRY(launch_collect_rescore(e, s));
+        }
+        // the count goes to a buffer the CONTEXT owns (sqe_stats reads it long after this index may be gone); the
+        // passes of a batch above MAX_PASS add up (r02: the last pass's count overwrote the others)
+        if (pass_index == 0) SQE_HIP(hipMemcpyAsync(c->unc_last.p, unc_count, 4, hipMemcpyDeviceToDevice, s));
+        else hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, s, c->unc_last.as<int>(), unc_count);
+        c->unc_valid.store(true);
+    return SQE_OK;
+}
+
 
 int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int nprobe, float* cos_out_dev, int64_t* id_out_dev,
                       hipStream_t s, int pass_index) {
@@ -444,6 +555,92 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         }
         SQE_HIP(hipMemsetAsync(idx->gmax.p, 0, gmax_bytes, s));
     }
+    int* unc_count = certify ? idx->unc.as<int>() : nullptr;
+    float* collect_thr = certify ? reinterpret_cast<float*>(idx->unc.as<int>() + 4) : nullptr;
+    // ---- int8 first pass (scan_mode INT8): threshold pass on a row sample (bf16 kernels, every step-th tile) -> fixed
+    // per-query collect thresholds -> int8 collect scan over all rows -> staged fp32 re-score + certificate -> the bf16
+    // collect pass for what is left.  Batches of <= 128 queries are HBM-bound in a 64- / 128-query tile the int8 kernel
+    // does not have; small indexes give the sample nothing to estimate from: both stay with the bf16 scan.
+    const int step8 = idx->i8_sample_step, m8 = idx->i8_sample_m;
+    const bool use_i8 = idx->scan_mode == SQE_SCAN_INT8_RESCORE && certify && plan.bn == 256 && K >= 256 && k <= m8 &&
+                        n_rows >= idx->i8_min_rows && n_rows >= (int64_t)step8 * SCAN_BM * 4;
+    if (use_i8) {
+        SQE_TRY(ensure_i8_copy(idx, s));
+        const int q8_pitch = K + 128;
+        const int n_tiles_s = (plan.n_tiles + step8 - 1) / step8;
+        ScanPlan ps = make_scan_plan((int64_t)n_tiles_s * SCAN_BM, B, auto_kp(idx, m8), c->cu_count, m8);
+        SQE_TRY(idx->q8.ensure((size_t)plan.b_pad * q8_pitch));
+        SQE_TRY(idx->q8sqi.ensure((size_t)plan.b_pad * 4));
+        SQE_TRY(idx->q8resid.ensure((size_t)plan.b_pad * 4));
+        SQE_TRY(idx->i8thr_int.ensure((size_t)plan.b_pad * 4));
+        SQE_TRY(idx->i8thr_eff.ensure((size_t)plan.b_pad * 4));
+        SQE_TRY(idx->i8cos_s.ensure((size_t)B * m8 * 4));
+        SQE_TRY(idx->i8ids_s.ensure((size_t)B * m8 * 8));
+        SQE_TRY(idx->i8stats.ensure(64));
+        {
+            StageTimer t(c->prof, s, ST_PREP);
+            if (plan.b_pad > B)
+                SQE_HIP(hipMemsetAsync(idx->q8.as<char>() + (size_t)B * q8_pitch, 0, (size_t)(plan.b_pad - B) * q8_pitch, s));
+            SQE_TRY(launch_quantize_queries_i8(idx->qn.as<float>(), B, K, idx->q8.as<int8_t>(), q8_pitch, idx->q8sqi.as<uint32_t>(),
+                                               idx->q8resid.as<float>(), s));
+            SQE_HIP(hipMemsetAsync(idx->i8stats.p, 0, 64, s));
+        }
+        {
+            // threshold pass: the bf16 scan + fp32 re-score of the row sample, top-m true cosines per query
+            StageTimer t(c->prof, s, ST_SAMPLE);
+            ScanArgs a;
+            a.db = idx->scan; a.q = idx->qb.as<bf16_t>(); a.n_rows = n_rows; a.K = K; a.B = B;
+            a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
+            a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
+            a.dbg_counters = nullptr;
+            a.q_resid = idx->q_resid.as<float>(); a.db_resid_max = idx->resid_max.as<uint32_t>();
+            a.collect_thr = nullptr; a.collect_keys = nullptr; a.collect_cnt = nullptr; a.unc_count = nullptr;
+            a.tile_step = step8;
+            SQE_TRY(launch_scan_bf16(ps, a, s));
+            SelectArgs sa;
+            sa.cand = idx->cand.as<uint64_t>(); sa.cand_cnt = idx->cand_cnt.as<int>();
+            sa.n_chunks = ps.n_chunks; sa.b_pad = ps.b_pad; sa.kp = ps.kp;
+            sa.master = idx->master; sa.qn = idx->qn.as<float>(); sa.K = K; sa.B = B; sa.k = m8;
+            sa.cos_out = idx->i8cos_s.as<float>(); sa.id_out = idx->i8ids_s.as<int64_t>(); sa.id_base = 0;
+            sa.q_resid = nullptr; sa.db_resid_max = nullptr; sa.unc_count = nullptr; sa.collect_thr = nullptr;
+            sa.gmax = nullptr; sa.gshift = -1;
+            SQE_TRY(launch_select_rescore(sa, s));
+            SQE_TRY(launch_i8_thresholds(idx->i8cos_s.as<float>(), m8, idx->q8sqi.as<uint32_t>(), K, B, plan.b_pad,
+                                         idx->i8thr_int.as<int>(), idx->i8thr_eff.as<float>(), s));
+        }
+        {
+            StageTimer t(c->prof, s, ST_SCAN);
+            I8ScanArgs ia;
+            ia.db8 = idx->i8db.as<int8_t>(); ia.tile_stride = idx->i8_tile_stride; ia.sxi = idx->i8sxi.as<uint32_t>();
+            ia.q8 = idx->q8.as<int8_t>(); ia.q_pitch = q8_pitch; ia.thr_int = idx->i8thr_int.as<int>();
+            ia.n_rows = n_rows; ia.K = K; ia.B = B; ia.b_pad = plan.b_pad; ia.n_tiles = plan.n_tiles; ia.n_chunks = plan.n_chunks;
+            ia.qblocks = plan.qblocks; ia.cand = idx->cand.as<uint64_t>(); ia.cand_cnt = idx->cand_cnt.as<int>();
+            SQE_TRY(launch_scan_i8(ia, s));
+        }
+        {
+            StageTimer t(c->prof, s, ST_SELECT);
+            I8SelectArgs sa;
+            sa.cand = idx->cand.as<uint64_t>(); sa.cand_cnt = idx->cand_cnt.as<int>(); sa.n_chunks = plan.n_chunks; sa.b_pad = plan.b_pad;
+            sa.master = idx->master; sa.qn = idx->qn.as<float>(); sa.K = K; sa.B = B; sa.k = k;
+            sa.sxi = idx->i8sxi.as<uint32_t>(); sa.sqi = idx->q8sqi.as<uint32_t>();
+            sa.q_resid8 = idx->q8resid.as<float>(); sa.db_resid8_max = idx->i8resid_max.as<uint32_t>();
+            sa.q_resid16 = idx->q_resid.as<float>(); sa.db_resid16_max = idx->resid_max.as<uint32_t>();
+            sa.thr_eff = idx->i8thr_eff.as<float>();
+            sa.sample_cos = idx->i8cos_s.as<float>(); sa.sample_ids = idx->i8ids_s.as<int64_t>(); sa.sample_m = m8;
+            sa.cos_out = cos_out_dev; sa.id_out = id_out_dev; sa.id_base = idx->id_base;
+            sa.unc_count = unc_count; sa.collect_thr = collect_thr;
+            sa.stats = idx->i8stats.as<unsigned long long>();
+            SQE_TRY(launch_select_i8(sa, s));
+        }
+        SQE_TRY(run_collect_fallback(idx, B, k, kp, plan.b_pad, unc_count, collect_thr, cos_out_dev, id_out_dev, pass_index, s));
+        SQE_HIP(hipMemcpyAsync(c->i8_last.p, idx->i8stats.p, 32, hipMemcpyDeviceToDevice, s));
+        c->i8_valid.store(true);
+        c->search_calls++;
+        c->last_scan_rows.store(n_rows);
+        c->last_scan_flops.store(2 * n_rows * (int64_t)K * B);
+        c->last_scan_bytes.store(n_rows * (int64_t)K + (int64_t)B * K * 4 + (int64_t)B * k * 12);   // SURVEY 8(d) with s = 1 byte per element
+        return SQE_OK;
+    }
     if (n_rows > 0) {
         StageTimer t(c->prof, s, ST_SCAN);
         ScanArgs a;
@@ -465,8 +662,6 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
     } else {
         SQE_HIP(hipMemsetAsync(idx->cand_cnt.p, 0, (size_t)plan.n_chunks * plan.b_pad * 4, s));
     }
-    int* unc_count = certify ? idx->unc.as<int>() : nullptr;
-    float* collect_thr = certify ? reinterpret_cast<float*>(idx->unc.as<int>() + 4) : nullptr;
     {
         StageTimer t(c->prof, s, ST_SELECT);
         SelectArgs sa;
@@ -479,51 +674,8 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         sa.unc_count = unc_count; sa.collect_thr = collect_thr;
         sa.gmax = (n_rows > 0 && plan.gshift >= 0) ? idx->gmax.as<uint32_t>() : nullptr; sa.gshift = plan.gshift;
         SQE_TRY(launch_select_rescore(sa, s));
-        // second pass for the queries whose certificate failed.  They are compacted into a dense batch on
-        // the device (no host round trip): the collect scan then costs what a batch of that size costs.
-        if (certify)
-            SQE_TRY(launch_compact_uncertified(collect_thr, B, idx->qb.as<bf16_t>(), idx->pitch, K * 2, idx->unc_ids.as<int>(),
-                                               idx->thr_c.as<float>(), plan.b_pad + 256, idx->qb_c.as<bf16_t>(), unc_count, s));
     }
-    if (certify) {
-        {
-            // The collect scans are scans: they are booked under scan_ms (scan_calls counts the main launches
-            // only).  One launch per range of counts is enqueued, each planned like a search of that batch size
-            // and returning at once unless the count is in its range (and at once when it is 0).
-            StageTimer t(c->prof, s, ST_COLLECT);
-            ScanArgs a;
-            a.db = idx->scan; a.q = idx->qb_c.as<bf16_t>(); a.n_rows = n_rows; a.K = K; a.B = B;
-            a.db_pitch = idx->pitch; a.q_pitch = idx->pitch;
-            a.cand = idx->cand.as<uint64_t>(); a.cand_cnt = idx->cand_cnt.as<int>(); a.gmax = idx->gmax.as<uint32_t>();
-            a.dbg_counters = nullptr;
-            a.q_resid = nullptr; a.db_resid_max = nullptr;
-            a.collect_thr = idx->thr_c.as<float>(); a.collect_keys = idx->fb_keys.as<uint64_t>(); a.collect_cnt = idx->fb_cnt.as<int>();
-            a.unc_count = unc_count;
-            const int bounds[5] = {0, 64, 256, 512, 1 << 30};
-            for (int r = 0; r < 4 && bounds[r] < B; ++r) {
-                const int hi = std::min(bounds[r + 1], B);
-                const ScanPlan cp = make_scan_plan(n_rows, hi, kp, c->cu_count);
-                a.collect_lo = bounds[r] + 1;
-                a.collect_hi = r == 3 ? (1 << 30) : bounds[r + 1];
-                SQE_TRY(launch_scan_collect(cp, a, s));
-            }
-        }
-        {
-            // ... and re-score them in fp32
-            StageTimer t(c->prof, s, ST_SELECT);
-            ExactArgs e;
-            e.master = idx->master; e.qn = idx->qn.as<float>(); e.K = K; e.B = B; e.k = k;
-            e.collect_thr = collect_thr; e.keys = idx->fb_keys.as<uint64_t>(); e.key_cnt = idx->fb_cnt.as<int>();
-            e.unc_ids = idx->unc_ids.as<int>(); e.unc_count = unc_count;
-            e.cos_out = cos_out_dev; e.id_out = id_out_dev; e.id_base = idx->id_base;
-            SQE_TRY(launch_collect_rescore(e, s));
-        }
-        // the count goes to a buffer the CONTEXT owns (sqe_stats reads it long after this index may be gone); the
-        // passes of a batch above MAX_PASS add up (r02: the last pass's count overwrote the others)
-        if (pass_index == 0) SQE_HIP(hipMemcpyAsync(c->unc_last.p, unc_count, 4, hipMemcpyDeviceToDevice, s));
-        else hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, s, c->unc_last.as<int>(), unc_count);
-        c->unc_valid.store(true);
-    }
+    if (certify) SQE_TRY(run_collect_fallback(idx, B, k, kp, plan.b_pad, unc_count, collect_thr, cos_out_dev, id_out_dev, pass_index, s));
     if (idx->dbg.p) {
         unsigned long long h[1024];
         SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, 8192, hipMemcpyDeviceToHost, s));
@@ -633,7 +785,10 @@ int sqe_index_search(sqe_index* idx, const float* q_host, int B, int k, int npro
 
 int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int iters, uint64_t seed) {
     if (!idx) return fail(SQE_ERR_INVALID, "null index");
-    if (idx->group) return fail(SQE_ERR_UNSUPPORTED, "sqe_index_train: IVF on a multi-device context is not built (flat indexes shard)");
+    if (idx->group) {
+        if (!x_dev || n <= 0) return fail(SQE_ERR_INVALID, "sqe_index_train: empty training set");
+        return group_index_train(idx, x_dev, n, iters, seed, true);
+    }
     if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_train: not an IVF index");
     if (!x_dev || n <= 0) return fail(SQE_ERR_INVALID, "sqe_index_train: empty training set");
     OpScope op(idx->ctx, idx->ord, false);
@@ -642,7 +797,10 @@ int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int it
 
 int sqe_index_train(sqe_index* idx, const float* x_host, int64_t n, int iters, uint64_t seed) {
     if (!idx) return fail(SQE_ERR_INVALID, "null index");
-    if (idx->group) return fail(SQE_ERR_UNSUPPORTED, "sqe_index_train: IVF on a multi-device context is not built (flat indexes shard)");
+    if (idx->group) {
+        if (!x_host || n <= 0) return fail(SQE_ERR_INVALID, "sqe_index_train: empty training set");
+        return group_index_train(idx, x_host, n, iters, seed, false);
+    }
     if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_train: not an IVF index");
     if (!x_host || n <= 0) return fail(SQE_ERR_INVALID, "sqe_index_train: empty training set");
     OpScope op(idx->ctx, idx->ord, true);
@@ -656,7 +814,11 @@ int sqe_index_train(sqe_index* idx, const float* x_host, int64_t n, int iters, u
 
 int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host) {
     if (!idx) return fail(SQE_ERR_INVALID, "null index");
-    if (idx->group || !idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_ivf_export: not an IVF index");
+    if (idx->group) {
+        if (!group_index_ivf_trained(idx)) return fail(SQE_ERR_STATE, "sqe_index_ivf_export: not a trained IVF index");
+        return group_index_ivf_export(idx, centroids_host, assign_host);
+    }
+    if (!idx->ivf) return fail(SQE_ERR_STATE, "sqe_index_ivf_export: not an IVF index");
     OpScope op(idx->ctx, idx->ord, true);
     return ivf_export(idx, idx->ivf, centroids_host, assign_host, op.s);
 }
@@ -715,9 +877,19 @@ int sqe_index_save(sqe_index* idx, const char* path) {
     h.version = 1; h.dim = (uint32_t)idx->dim; h.kind = (uint32_t)idx->kind; h.nlist = (uint32_t)idx->nlist;
     if (idx->group) {
         SQE_TRY(group_index_count(idx, &h.n));
-        h.id_base = idx->id_base; h.flags = 0; h.certify = (uint32_t)idx->certify;
+        const bool givf = group_index_ivf_trained(idx);
+        h.id_base = idx->id_base; h.flags = givf ? 1u : 0u; h.certify = (uint32_t)idx->certify;
         if (fwrite(&h, 1, sizeof(h), fc.f) != sizeof(h)) return fail(SQE_ERR_IO, "sqe_index_save: short write");
         SQE_TRY(group_index_save_rows(idx, fc.f, pin.p, IO_CHUNK));
+        if (givf) {
+            // the same IVF section a single-device index writes: centroids, then the list of every row in global order
+            std::vector<float> cent((size_t)idx->nlist * idx->dim);
+            std::vector<int32_t> assign((size_t)std::max<int64_t>(h.n, 1));
+            SQE_TRY(group_index_ivf_export(idx, cent.data(), assign.data()));
+            if (fwrite(cent.data(), 4, cent.size(), fc.f) != cent.size()) return fail(SQE_ERR_IO, "sqe_index_save: short write");
+            if (h.n > 0 && fwrite(assign.data(), 4, (size_t)h.n, fc.f) != (size_t)h.n)
+                return fail(SQE_ERR_IO, "sqe_index_save: short write");
+        }
         if (fflush(fc.f) != 0) return fail(SQE_ERR_IO, "sqe_index_save: flush failed");
         return SQE_OK;
     }
@@ -750,7 +922,6 @@ int sqe_index_load(sqe_ctx* ctx, const char* path, sqe_index** out) {
     if (fread(&h, 1, sizeof(h), fc.f) != sizeof(h) || memcmp(h.magic, "SQEIDX01", 8) != 0 || h.version != 1)
         return fail(SQE_ERR_IO, "sqe_index_load: not a saved index (bad header)");
     if (h.n < 0 || h.dim == 0 || h.dim % 64 != 0) return fail(SQE_ERR_IO, "sqe_index_load: corrupt header");
-    if (ctx->group && (h.flags & 1u)) return fail(SQE_ERR_UNSUPPORTED, "sqe_index_load: an IVF index cannot be loaded into a multi-device context");
     sqe_index* idx = nullptr;
     SQE_TRY(sqe_index_create(ctx, (int)h.dim, (int)h.kind, (int)h.nlist, &idx));
     struct Guard {
@@ -769,6 +940,13 @@ int sqe_index_load(sqe_ctx* ctx, const char* path, sqe_index** out) {
             const int64_t m = std::min(rows_per_step, h.n - off);
             if (fread(pin.p, row_bytes, (size_t)m, fc.f) != (size_t)m) return fail(SQE_ERR_IO, "sqe_index_load: file is truncated");
             SQE_TRY(group_index_add(idx, (const float*)pin.p, m, false, true));   // synchronises: the pinned buffer is reused
+        }
+        if (h.flags & 1u) {
+            if (idx->kind != SQE_INDEX_IVF_FLAT) return fail(SQE_ERR_IO, "sqe_index_load: IVF section in a flat index file");
+            const size_t cb = (size_t)h.nlist * row_bytes, ab = (size_t)h.n * 4;
+            std::vector<char> host(cb + ab);
+            if (fread(host.data(), 1, cb + ab, fc.f) != cb + ab) return fail(SQE_ERR_IO, "sqe_index_load: file is truncated");
+            SQE_TRY(group_index_ivf_restore(idx, (const float*)host.data(), (const int32_t*)(host.data() + cb), h.n));
         }
         guard.i = nullptr;
         *out = idx;
@@ -945,7 +1123,15 @@ static int stats_accumulate(sqe_ctx* ctx, sqe_stats_t* out) {
         out->add_ms += ctx->prof.ms[ST_ADD];
         out->encode_ms += ctx->prof.ms[ST_ENCODE];
         out->cache_ms += ctx->prof.ms[ST_CACHE];
+        out->sample_ms += ctx->prof.ms[ST_SAMPLE];
         out->scan_calls += ctx->prof.calls[ST_SCAN];
+    }
+    if (ctx->i8_valid.load()) {
+        unsigned long long v[4] = {0, 0, 0, 0};
+        SQE_HIP(hipDeviceSynchronize());
+        if (hipMemcpy(v, ctx->i8_last.p, 32, hipMemcpyDeviceToHost) == hipSuccess) {
+            out->i8_collected += (int64_t)v[0]; out->i8_rescored += (int64_t)v[1]; out->i8_overflows += (int64_t)v[2];
+        }
     }
     if (ctx->unc_valid.load()) {
         // the count was written on the stream of that search; a device-wide wait orders this read after it

@@ -208,23 +208,27 @@ int group_describe(sqe_ctx* leader, int* n_shards, int* exchange, int* device_id
 int group_index_create(sqe_ctx* leader, int dim, int kind, int nlist, sqe_index** out) {
     *out = nullptr;
     Group* g = leader->group;
-    if (kind != SQE_INDEX_FLAT)
-        return fail(SQE_ERR_UNSUPPORTED, "sqe_index_create: a multi-device context shards FLAT indexes only");
-    (void)nlist;
+    if (kind != SQE_INDEX_FLAT && kind != SQE_INDEX_IVF_FLAT) return fail(SQE_ERR_INVALID, "sqe_index_create: unknown index kind");
+    if (kind == SQE_INDEX_IVF_FLAT && (nlist < 1 || nlist > (1 << 20)))
+        return fail(SQE_ERR_INVALID, "sqe_index_create: IVF needs 1 <= nlist <= 2^20");
     std::unique_ptr<sqe_index> idx(new (std::nothrow) sqe_index);
     std::unique_ptr<GroupIndex> gi(new (std::nothrow) GroupIndex);
     if (!idx || !gi) return fail(SQE_ERR_OOM, "sqe_index_create: host allocation failed");
     idx->ctx = leader;
     idx->dim = dim;
     idx->kind = kind;
+    idx->nlist = kind == SQE_INDEX_IVF_FLAT ? nlist : 0;
     SQE_HIP(hipSetDevice(leader->device));
     SQE_TRY(idx->ord.init());
     SQE_HIP(hipEventCreateWithFlags(&gi->ev_q, hipEventDisableTiming));
     idx->group = gi.release();
     sqe_index* raw = idx.release();
+    const int idx_nlist = raw->nlist;
     for (int p = 0; p < g->P; ++p) {
         sqe_index* sh = nullptr;
-        int rc = index_create_impl(g->members[p], dim, SQE_INDEX_FLAT, 0, false, &sh);
+        // IVF: every shard is a complete IVF index over ITS rows with the same (replicated) centroids --
+        // lists are sharded by the group's row ownership, the [B,k] exchange and the merge are the flat index's
+        int rc = index_create_impl(g->members[p], dim, kind, idx_nlist, false, &sh);
         if (rc != SQE_OK) { group_index_destroy(raw); return rc; }
         raw->group->shards.push_back(sh);
         raw->group->qbuf.emplace_back(new DevBuf);
@@ -401,6 +405,96 @@ int group_index_set_option(sqe_index* idx, const char* key, double value) {
     }
     for (sqe_index* sh : idx->group->shards) SQE_TRY(sqe_index_set_option(sh, key, value));
     if (k == "certify") idx->certify = value != 0.0;
+    return SQE_OK;
+}
+
+// ---------------------------------------------------------------- IVF on a device group
+// Training runs ONCE, on the leader's shard (k-means over the sample), and the normalised centroids are then
+// replicated: every other shard takes them bit for bit (ivf_restore) and assigns its own rows.  All shards therefore
+// probe the same lists in the same order, a shard scans the rows it owns of every probed list, and the merged result is
+// the IVF search over the global lists.  x: the training sample, host or LEADER-device memory.
+int group_index_train(sqe_index* idx, const float* x, int64_t n, int iters, uint64_t seed, bool x_on_device) {
+    Group* g = idx->ctx->group;
+    GroupIndex* gi = idx->group;
+    const int P = g->P, dim = idx->dim, nlist = idx->nlist;
+    if (idx->kind != SQE_INDEX_IVF_FLAT) return fail(SQE_ERR_STATE, "sqe_index_train: not an IVF index");
+    GroupScope sc(idx, !x_on_device);        // a device block is the caller's work on the leader's context stream (= sc.s(0))
+    SQE_HIP(hipSetDevice(g->devs[0]));
+    sqe_index* lead = gi->shards[0];
+    {
+        DevBuf tmp;
+        const float* xd = x;
+        if (!x_on_device) {
+            SQE_TRY(tmp.ensure((size_t)n * dim * 4));
+            SQE_HIP(hipMemcpyAsync(tmp.p, x, (size_t)n * dim * 4, hipMemcpyHostToDevice, sc.s(0)));
+            xd = tmp.as<float>();
+        }
+        SQE_TRY(ivf_train(lead, lead->ivf, xd, n, iters, seed, sc.s(0)));
+        SQE_HIP(hipStreamSynchronize(sc.s(0)));
+    }
+    // replicate: leader -> host -> every member (16 MB at nlist 4096 x 1024; once per training)
+    const size_t cb = (size_t)nlist * dim * 4;
+    std::vector<float> cent(cb / 4);
+    SQE_HIP(hipMemcpyAsync(cent.data(), ivf_coarse(lead->ivf)->master, cb, hipMemcpyDeviceToHost, sc.s(0)));
+    SQE_HIP(hipStreamSynchronize(sc.s(0)));
+    for (int p = 1; p < P; ++p) {
+        SQE_HIP(hipSetDevice(g->devs[p]));
+        sqe_index* sh = gi->shards[p];
+        SQE_TRY(gi->stage[p]->ensure(cb));
+        SQE_HIP(hipMemcpyAsync(gi->stage[p]->p, cent.data(), cb, hipMemcpyHostToDevice, sc.s(p)));
+        SQE_TRY(ivf_restore(sh, sh->ivf, gi->stage[p]->as<float>(), nullptr, 0, sc.s(p)));   // no assignments yet ...
+        SQE_TRY(ivf_rows_added(sh, sh->ivf, sc.s(p)));                                          // ... the shard makes its own
+    }
+    return sync_all(sc, g);
+}
+
+// centroids [nlist, dim] (the leader's = everyone's) and the list of every stored row in GLOBAL row order
+int group_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host) {
+    Group* g = idx->ctx->group;
+    GroupIndex* gi = idx->group;
+    const int P = g->P;
+    if (idx->kind != SQE_INDEX_IVF_FLAT) return fail(SQE_ERR_STATE, "sqe_index_ivf_export: not an IVF index");
+    GroupScope sc(idx, true);
+    std::vector<int32_t> part;
+    for (int p = 0; p < P; ++p) {
+        SQE_HIP(hipSetDevice(g->devs[p]));
+        sqe_index* sh = gi->shards[p];
+        const int64_t m = sh->n.load();
+        part.resize((size_t)std::max<int64_t>(m, 1));
+        SQE_TRY(ivf_export(sh, sh->ivf, p == 0 ? centroids_host : nullptr, assign_host ? part.data() : nullptr, sc.s(p)));
+        if (assign_host)
+            for (int64_t i = 0; i < m; ++i) assign_host[i * P + p] = part[(size_t)i];      // local row i of shard p = global row i * P + p
+    }
+    SQE_HIP(hipSetDevice(g->devs[0]));
+    return SQE_OK;
+}
+
+bool group_index_ivf_trained(sqe_index* idx) {
+    return idx->kind == SQE_INDEX_IVF_FLAT && idx->group->shards[0]->ivf && ivf_trained(idx->group->shards[0]->ivf);
+}
+
+// sqe_index_load: centroids and the per-row assignment in GLOBAL row order (host) -> every shard's share
+int group_index_ivf_restore(sqe_index* idx, const float* centroids_host, const int32_t* assign_host, int64_t n) {
+    Group* g = idx->ctx->group;
+    GroupIndex* gi = idx->group;
+    const int P = g->P, dim = idx->dim, nlist = idx->nlist;
+    GroupScope sc(idx, true);
+    const size_t cb = (size_t)nlist * dim * 4;
+    std::vector<int32_t> part;
+    for (int p = 0; p < P; ++p) {
+        SQE_HIP(hipSetDevice(g->devs[p]));
+        sqe_index* sh = gi->shards[p];
+        const int64_t m = sh->n.load();
+        if (m != shard_rows_of(n, P, p)) return fail(SQE_ERR_STATE, "sqe_index_load: shard sizes do not match the file");
+        part.resize((size_t)std::max<int64_t>(m, 1));
+        for (int64_t i = 0; i < m; ++i) part[(size_t)i] = assign_host[i * P + p];
+        SQE_TRY(gi->stage[p]->ensure(cb + (size_t)std::max<int64_t>(m, 1) * 4));
+        SQE_HIP(hipMemcpyAsync(gi->stage[p]->p, centroids_host, cb, hipMemcpyHostToDevice, sc.s(p)));
+        SQE_HIP(hipMemcpyAsync(gi->stage[p]->as<char>() + cb, part.data(), (size_t)m * 4, hipMemcpyHostToDevice, sc.s(p)));
+        SQE_TRY(ivf_restore(sh, sh->ivf, gi->stage[p]->as<float>(), (const int32_t*)(gi->stage[p]->as<char>() + cb), m, sc.s(p)));
+        SQE_HIP(hipStreamSynchronize(sc.s(p)));           // `part` is reused
+    }
+    SQE_HIP(hipSetDevice(g->devs[0]));
     return SQE_OK;
 }
 

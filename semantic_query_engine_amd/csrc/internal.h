@@ -52,7 +52,7 @@ struct DevBuf {
 };
 
 // ---------------------------------------------------------------- profiling
-enum Stage { ST_SCAN = 0, ST_PREP, ST_SELECT, ST_ADD, ST_ENCODE, ST_CACHE, ST_COLLECT, ST_COUNT };
+enum Stage { ST_SCAN = 0, ST_PREP, ST_SELECT, ST_ADD, ST_ENCODE, ST_CACHE, ST_COLLECT, ST_SAMPLE, ST_COUNT };
 
 // hipEvent pairs around the stages, on whatever stream the stage ran on; totals are read by sqe_stats.
 struct Profiler {
@@ -159,6 +159,8 @@ struct sqe_ctx {
     sqe::DevBuf unc_last;    // 16 B owned by the context: uncertified-query count of the last certified search
                              //   (copied on the search's stream; never a pointer into an index's buffers)
     std::atomic<bool> unc_valid{false};
+    sqe::DevBuf i8_last;     // 32 B: keys collected / rows re-scored / overflows / uncertified of the last int8 search
+    std::atomic<bool> i8_valid{false};
     sqe::DevBuf cache_tmp;   // one-shot cosine scan: matrix + q + sims + best
     sqe::Group* group = nullptr;                // n_dev > 1: this context leads a device group (group.hip)
 };
@@ -191,6 +193,16 @@ struct sqe_index {
     sqe::DevBuf unc_ids, thr_c, qb_c;   // uncertified queries compacted into a dense batch: ids, thresholds, bf16 rows
     sqe::DevBuf stage_in, stage_out;    // H2D / D2H staging of the host entry points
     int certify = 1;               // run the exactness certificate + fp32 rescan fallback
+    // ---- int8 first pass (scan_mode == SQE_SCAN_INT8_RESCORE; quant.hip, scan_i8.hip, select_i8.hip)
+    sqe::DevBuf i8db;              // tiled int8 copy: tile t (256 rows) at t * i8_tile_stride
+    sqe::DevBuf i8sxi;             // [i8_cap_tiles * 256] u32 row scales
+    sqe::DevBuf i8resid_max;       // u32 float bits: max over rows of || x_hat - sxi unit x8 ||
+    int64_t i8_cap_tiles = 0, i8_tile_stride = 0;
+    int64_t i8_rows = 0;           // rows [0, i8_rows) of the int8 copy are current (filled lazily by the first search after an add)
+    sqe::DevBuf q8, q8sqi, q8resid, i8thr_int, i8thr_eff, i8cos_s, i8ids_s, i8stats;   // per search
+    int64_t i8_min_rows = 1000000; // below this many rows (or batches <= 128, dim < 256, k > 32) the bf16 scan answers
+    int i8_sample_step = 50;       // the threshold pass scans every i8_sample_step-th tile with the bf16 kernels ...
+    int i8_sample_m = 32;          // ... and the collect threshold of a query is its m-th best true cosine there
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
     bool internal = false;         // sub-index of another object (IVF coarse quantiser): runs under its owner's lock and stream
     sqe::GroupIndex* group = nullptr;   // index of a multi-device context: one shard per member device (group.hip)
@@ -266,6 +278,10 @@ int group_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, fl
 int group_index_set_option(sqe_index* idx, const char* key, double value);
 int group_index_search(sqe_index* idx, const float* q, int B, int k, int nprobe, float* cos_out, int64_t* id_out, bool on_device);
 int group_index_save_rows(sqe_index* idx, FILE* f, void* pinned, size_t pinned_bytes);
+int group_index_train(sqe_index* idx, const float* x, int64_t n, int iters, uint64_t seed, bool x_on_device);
+int group_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host);
+bool group_index_ivf_trained(sqe_index* idx);
+int group_index_ivf_restore(sqe_index* idx, const float* centroids_host, const int32_t* assign_host, int64_t n);
 int group_describe(sqe_ctx* leader, int* n_shards, int* exchange, int* device_ids, int cap);
 int group_member_count(const sqe_ctx* leader);          // shards of the context (1 without a group)
 sqe_ctx* group_member(sqe_ctx* leader, int p);          // member context p (0 = the leader itself)

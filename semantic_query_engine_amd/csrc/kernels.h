@@ -79,6 +79,7 @@ struct ScanArgs {
     int* collect_cnt;
     const int* unc_count;
     int collect_lo, collect_hi;   // collect pass: this launch runs when collect_lo <= *unc_count <= collect_hi
+    int tile_step = 1;            // > 1: scan DB tiles 0, step, 2 step, ... only (plan.n_tiles counts the scanned tiles); row ids stay global
 };
 int launch_scan_bf16(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
 // ping-pong form for 256-query blocks (scan_pp.hip, the default): the two waves of a SIMD alternate between
@@ -87,6 +88,43 @@ int launch_scan_bf16_pp(const ScanPlan& plan, const ScanArgs& args, hipStream_t 
 // second pass for uncertified queries: same scan, fixed thresholds args.collect_thr, every row at or
 // above its query's threshold goes to args.collect_keys; exits at once when *args.unc_count == 0
 int launch_scan_collect(const ScanPlan& plan, const ScanArgs& args, hipStream_t stream);
+
+// ------------------------------------------------------------------ int8 first-pass scan (quant.hip, scan_i8.hip, select_i8.hip)
+// Scale unit of the int8 copies of `dim`-d unit vectors: row scale = sxi * unit (quant.hip).
+float i8_scale_unit(int dim);
+// int8 copy of master rows [first_row, first_row + n) (rows != null: of the listed rows) into the TILED layout
+// (tile t at t * tile_stride; K slice h of row r at h * 16 KiB + (r % 256) * 64), row scales sxi[row], atomic max of the
+// rounding residual || x_hat - sxi unit x8 || (float bits).
+int launch_quantize_rows_i8(const float* master, const int64_t* rows, int64_t first_row, int64_t n, int dim, int8_t* out,
+                            int64_t tile_stride, uint32_t* sxi, uint32_t* resid_max, hipStream_t stream);
+// int8 copy of normalised query rows, row-major at q_pitch bytes; sqi[q], resid_rows[q]
+int launch_quantize_queries_i8(const float* qn, int B, int dim, int8_t* out, int q_pitch, uint32_t* sqi, float* resid_rows, hipStream_t stream);
+// collect thresholds from the sample pass: tau[q] = cos_s[q][m - 1] (true cosines, best first)
+int launch_i8_thresholds(const float* cos_s, int m, const uint32_t* sqi, int dim, int B, int b_pad, int* thr_int, float* thr_eff,
+                         hipStream_t stream);
+struct I8ScanArgs {
+    const int8_t* db8; int64_t tile_stride; const uint32_t* sxi;
+    const int8_t* q8; int q_pitch; const int* thr_int;
+    int64_t n_rows; int K, B, b_pad, n_tiles, n_chunks, qblocks;
+    uint64_t* cand; int* cand_cnt;      // the bf16 scan's candidate lists: [n_chunks, b_pad, CAND_CAP], [n_chunks, b_pad]
+};
+int launch_scan_i8(const I8ScanArgs& args, hipStream_t stream);
+// Per query: gather the collected keys, fp32 re-score in two stages (the best 64 by int8 score give t = k-th true cosine so
+// far, then every collected row whose int8 score can still reach t), exact top-k, certificate thr_eff + eps < k-th cosine.
+// collect_thr[q] = +inf if certified, else (k-th cosine so far) - bf16 eps: the input of the bf16 collect pass (exact.hip).
+struct I8SelectArgs {
+    const uint64_t* cand; const int* cand_cnt; int n_chunks, b_pad;
+    const float* master; const float* qn; int K, B, k;
+    const uint32_t* sxi; const uint32_t* sqi;                 // row / query scales
+    const float* q_resid8; const uint32_t* db_resid8_max;     // int8 residuals (eps of the certificate)
+    const float* q_resid16; const uint32_t* db_resid16_max;   // bf16 residuals (threshold of the fallback)
+    const float* thr_eff;                                     // [b_pad] estimated-score bound of an uncollected row
+    const float* sample_cos; const int64_t* sample_ids; int sample_m;   // threshold pass: top-m true cosines / rows of the sample, best first
+    float* cos_out; int64_t* id_out; int64_t id_base;
+    int* unc_count; float* collect_thr;
+    unsigned long long* stats;                                 // null or [4]: keys gathered, rows re-scored, overflows, uncertified
+};
+int launch_select_i8(const I8SelectArgs& args, hipStream_t stream);
 
 // ------------------------------------------------------------------ select + rescore (S3+S4)
 struct SelectArgs {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(THREADS) void scan_bf16_kernel(ScanKernelArgs p) {
     const int total_stages = n_entries * KS;
     const char* qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ldB;
     const char* dbbase = reinterpret_cast<const char*>(p.db);
-    auto tile_of = [&](int e) { return e < nt ? tile_begin + e : tile_begin; };
+    auto tile_of = [&](int e) { return (e < nt ? tile_begin + e : tile_begin) * p.tile_step; };
     // K step ks covers k slice (ks + rot) mod KS: query blocks sharing a DB tile walk K in rotated
     // order and touch the same DB lines one K step apart (the dot product is order independent)
     const int rot = (logical * p.krot) % KS;
@@ -332,6 +332,7 @@ ScanKernelArgs make_kernel_args(const ScanPlan& plan, const ScanArgs& a) {
         k.krot = krot;
         k.dbg = dbg;
     }
+    k.tile_step = a.tile_step > 0 ? a.tile_step : 1;
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.gmax = a.gmax; k.dbg_counters = a.dbg_counters;
     k.collect_thr = nullptr; k.collect_keys = nullptr; k.collect_cnt = nullptr; k.unc_count = nullptr;
     k.collect_lo = 0; k.collect_hi = 0;

@@ -58,6 +58,7 @@ struct ScanKernelArgs {
     int k_rows;          // > 0 (then gshift_k == 2, k <= 16): the k-row bound is the k-th largest of the 16 quad maxima, not their minimum
     const float* q_resid;            // [B] error-bound inputs of the k-row bound (kernels.h: scan_eps)
     const uint32_t* db_resid_max;
+    int tile_step;       // scanned tile t is DB tile t * tile_step (1: every tile; > 1: the row sample of the int8 path's threshold pass)
     int krot;            // workgroup w walks K rotated by w * krot steps
     int dbg;             // timing experiments only (SQE_DBG): 1 = no MFMA / LDS reads, 2 = no DMA in the loop, 4 = no filter,
                          //   8 = no global-bound refresh, 16 = filter fast path only

@@ -1,0 +1,453 @@
+// scan_i8.hip -- int8 first-pass scan for query blocks of 256 (gfx950): v_mfma_i32_16x16x64_i8 at twice the bf16 MFMA rate
+// (measured, tools/micro/mfma_power.hip: 4.2-4.3 POP/s on Gaussian int8 rows against 2.07-2.11 PFLOP/s bf16, same clock).
+//
+// What the scan computes.  scores = X8 . Q8^T in exact integer arithmetic over the int8 copies of the L2-normalised rows
+// (quant.hip: symmetric per-row scales); acc * sxi[row] * (S0^2 * sqi[query]) estimates the cosine to within the
+// deterministic bound scan_eps(dq8, dx8max) -- ~0.02 on 1024-d Gaussian rows, eight times the bf16 bound.  With an error
+// band that wide an adaptive top-k filter cannot be selective (every row within 2 eps of the k-th place would have to be
+// kept), so this kernel does not rank: it COLLECTS.  Every query carries a fixed integer threshold, derived before the
+// launch from the true cosines of a 2 % row sample (api.hip: the m-th best of the sample sits ~1 sigma below the k-th best of
+// the index), and every row whose scaled score reaches it is appended to the (chunk, query) list -- the candidate lists and
+// LDS slot counters of the bf16 scan, without compaction, bound exchange or boot pass.  select_i8.hip then re-scores the
+// collected rows in fp32 and proves per query that no uncollected row can reach the k-th cosine:
+// thr_eff + eps < k-th true cosine.  Queries whose proof fails (or whose lists overflowed) take the bf16 collect pass that
+// already backs the bf16 certificate.  Results are therefore the exact fp32 top-k whatever the int8 rounding did.
+//
+// Schedule: the ping-pong schedule of scan_pp.hip byte for byte -- a half-step is 64 int8 elements = 64 B per row, the same
+// LDS image, swizzle, DMA pieces and ds_read_b128 addresses as 32 bf16 elements -- with these differences:
+//   * DB tiles are read from the TILED int8 copy: a half-step is one contiguous 16 KiB block (quant.hip);
+//   * the last half-step of a tile issues its MFMAs fragment row by fragment row and multiplies the finished accumulators
+//     of the previous fragment row by their rows' scales (v_mul_i32_i24, under the MFMAs of the next row), folding the
+//     products into four running maxima; a wave whose maxima reach a threshold marks the tile;
+//   * marked tiles run the append path in one common phase (no cross-wave step follows it: no compaction exists);
+//   * the 256 row scales of a tile (1 KiB) arrive through one extra LDS-DMA piece per tile.
+#include <stdlib.h>
+
+#include "scan_common.h"
+
+namespace sqe {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr int HALF_BYTES = 64;                     // bytes per row per half-step (64 int8 elements)
+constexpr int LINE_BYTES = 128;                    // LDS line: the slices of tile rows L and L + 128
+constexpr int OPER_BYTES = 128 * LINE_BYTES;       // 16 KiB: one operand of one half-step
+constexpr int STAGE_BYTES = 2 * OPER_BYTES;        // DB rows, then queries
+constexpr int NSTAGE = 4;
+constexpr int BNQ = 256;
+constexpr int OFF_SCALES = NSTAGE * STAGE_BYTES;   // 2 x [256] u32 row scales (tile parity)
+constexpr int OFF_CNT = OFF_SCALES + 2 * 1024;     // int [256] list lengths of this workgroup's queries
+constexpr int OFF_FLAGS = OFF_CNT + BNQ * 4;       // int [16]
+constexpr int LDS_BYTES = OFF_FLAGS + 64;
+constexpr int BLOCK_BYTES = SCAN_BM * HALF_BYTES;  // 16 KiB: one half-step of a tiled DB tile
+
+struct I8KernelArgs {
+    const int8_t* db8;        // tiled int8 copy
+    long long tile_stride;    // bytes between tiles
+    const uint32_t* sxi;      // [rows] row scales (multiples of S0)
+    const int8_t* q8;         // [b_pad] query rows, row-major
+    int q_pitch;
+    const int* thr_int;       // [b_pad] collect thresholds on acc * sxi
+    int64_t n_rows;
+    int K, B, b_pad, n_tiles, n_chunks, qblocks;
+    uint64_t* cand;           // [n_chunks, b_pad, CAND_CAP]
+    int* cand_cnt;            // [n_chunks, b_pad]: entries APPENDED (may exceed CAND_CAP: the list overflowed)
+    int dbg;
+};
+
+#define I8_BARRIER()                           \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+#define I8_WAIT(imm)                               \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_waitcnt(imm);           \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+// gfx9 encoding: vmcnt in [3:0] and [15:14], expcnt [6:4] left at its maximum, lgkmcnt [11:8]
+#define I8_WAIT_VM8_LGKM0() I8_WAIT(0x0078)
+#define I8_WAIT_VM7_LGKM0() I8_WAIT(0x0077)
+#define I8_WAIT_VM0_LGKM0() I8_WAIT(0x0070)
+
+typedef i32x4 AOps[8];    // [fm]: 128 rows x 64 k (16 int8 per lane and fragment)
+typedef i32x4 BOps[4];    // [fn]:  64 queries x 64 k
+
+struct Cur {              // a half-step: (tile entry, 64-wide slice inside it)
+    int e, h;
+    const char* tile;
+};
+
+struct S8 {
+    const char* qbase;
+    const char* scales_src;                // sxi of tile 0 of the chunk, as bytes
+    char* smem;
+    unsigned offA0, offA1, offB0, offB1;   // per-lane source offsets of this wave's DMA pieces
+    unsigned rdA, rdB;                     // per-lane LDS offsets of the operand reads inside a stage
+    int wave, wm, wn, lane;
+    int nt, HS, J;
+    long long tile_bytes;
+    Cur rd, dm;
+    int order;
+    int pend_h, pend_stage;
+    bool defer_on;
+
+    __device__ __forceinline__ void advance(Cur& c) const {
+        if (++c.h == HS) {
+            c.h = 0;
+            ++c.e;
+            c.tile += tile_bytes;
+        }
+    }
+    __device__ __forceinline__ void issue_a(const Cur& c, int stage) const {
+        char* st = smem + stage * STAGE_BYTES;
+        const char* as = c.tile + (long long)c.h * BLOCK_BYTES;
+        lds_dma16(as + offA0, st + wave * 1024);
+        lds_dma16(as + offA1, st + (wave + 8) * 1024);
+    }
+    __device__ __forceinline__ void issue_b(int h, int stage, int piece) const {
+        char* st = smem + stage * STAGE_BYTES + OPER_BYTES;
+        const char* bs = qbase + h * HALF_BYTES;
+        if (piece == 0) lds_dma16(bs + offB0, st + wave * 1024);
+        else lds_dma16(bs + offB1, st + (wave + 8) * 1024);
+    }
+    // this wave's pieces of half-step c (+ the row scales of c's tile, once per tile, from wave 0)
+    __device__ __forceinline__ void issue(const Cur& c, int stage, bool all) const {
+        if (wave == 0 && c.h == 0) lds_dma16(scales_src + (long long)c.e * 1024 + lane * 16, smem + OFF_SCALES + (c.e & 1) * 1024);
+        issue_a(c, stage);
+        issue_b(c.h, stage, 0);
+        if (all) issue_b(c.h, stage, 1);
+    }
+};
+
+template <bool FIRST>
+__device__ __forceinline__ void cmp_phase(i32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+            acc[fm][fn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[fm], b[fn], FIRST ? i32x4{0, 0, 0, 0} : acc[fm][fn], 0, 0, 0);
+}
+
+// middle compute phase that also issues the one DMA piece its wave's preceding memory phase left over (scan_pp.hip)
+__device__ __forceinline__ void cmp_phase_mid(S8& P, i32x4 (&acc)[8][4], const AOps& a, const BOps& b) {
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+        if (fm == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (P.pend_h >= 0) {
+                P.issue_b(P.pend_h, P.pend_stage, 1);
+                P.pend_h = -1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+    }
+}
+
+// Last half-step of a tile: MFMAs fragment row by fragment row; the 16 accumulators of fragment row fm - 1 are final by
+// then and are multiplied IN PLACE by the scales of their four rows (|acc| < 2^23 and scale < 2^16 by construction, the
+// product -- a cosine in units of S0^2 sqi -- below 2^31: quant.hip) and folded into the running maximum of their column
+// group.  Returns the wave-uniform mask of the column groups whose maximum reaches its query's threshold.
+__device__ __forceinline__ unsigned cmp_phase_last(i32x4 (&acc)[8][4], const AOps& a, const BOps& b, const i32x4* scales, const int (&thr)[4]) {
+    int mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    i32x4 sc[8];
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) sc[fm] = scales[fm * 4];          // rows fm * 16 + (lane >> 4) * 4 + 0..3: 16 B, fragments 64 B apart
+    auto finish = [&](int fm) {
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[fm][fn][r] = __mul24(acc[fm][fn][r], sc[fm][r]);
+            mx[fn] = max(max(mx[fn], acc[fm][fn][0]), acc[fm][fn][1]);
+            mx[fn] = max(max(mx[fn], acc[fm][fn][2]), acc[fm][fn][3]);
+        }
+    };
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+        if (fm > 0) finish(fm - 1);
+    }
+    finish(7);
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mask |= __any(mx[j] >= thr[j]) ? (1u << j) : 0u;
+    return __builtin_amdgcn_readfirstlane(mask);
+}
+
+__device__ __forceinline__ void read_operands(const S8& P, AOps& a, BOps& b, int j) {
+    const char* st = P.smem + (j & 3) * STAGE_BYTES;
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const i32x4*>(st + P.rdA + fm * 2048);
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const i32x4*>(st + OPER_BYTES + P.rdB + fn * 2048);
+}
+
+// MEMORY phase of half-step j (= P.rd): DMA of half-step j + 3 into the stage half-step j - 1 used, operand reads of
+// half-step j, counted wait that retires this wave's pieces of half-step j + 1 (scan_pp.hip: mem_lean / mem_phase).
+__device__ __forceinline__ void mem_phase(S8& P, AOps& a, BOps& b, int j, bool defer) {
+    const bool more = j + 3 < P.J;
+    const int stage = (j + 3) & 3;
+    const bool all = !(defer && more);
+    if (P.order == 0) {
+        if (more) P.issue(P.dm, stage, all);
+        read_operands(P, a, b, j);
+    } else {
+        read_operands(P, a, b, j);
+        if (more) P.issue(P.dm, stage, all);
+    }
+    if (more && !all) {
+        P.pend_h = P.dm.h;
+        P.pend_stage = stage;
+    }
+    if (!more) I8_WAIT_VM0_LGKM0();
+    else if (all) I8_WAIT_VM8_LGKM0();
+    else I8_WAIT_VM7_LGKM0();
+    P.advance(P.rd);
+    if (more) P.advance(P.dm);
+}
+
+__device__ __forceinline__ uint64_t make_key_i32(int score, uint32_t row) {
+    return ((uint64_t)((uint32_t)score ^ 0x80000000u) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+
+// accumulator t (fragment t >> 2, element t & 3) of column group J, t uniform (scan_common.h: pick_acc)
+template <int J>
+__device__ __forceinline__ int pick_acc_i32(const i32x4 (&acc)[8][4], int t) {
+    int v = 0;
+#define SQE_PICK(n) \
+    case n: asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(acc[(n) >> 2][J][(n) & 3])); break;
+#define SQE_PICK4(n) SQE_PICK(n) SQE_PICK((n) + 1) SQE_PICK((n) + 2) SQE_PICK((n) + 3)
+    switch (t) {
+        SQE_PICK4(0) SQE_PICK4(4) SQE_PICK4(8) SQE_PICK4(12) SQE_PICK4(16) SQE_PICK4(20) SQE_PICK4(24) SQE_PICK4(28)
+        default: break;
+    }
+#undef SQE_PICK4
+#undef SQE_PICK
+    return v;
+}
+
+// append path of one column group of a finished tile (scan_common.h: filter_group, integer scores, no compaction)
+template <int J>
+__device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t row_base, int64_t n_rows, bool partial, int qcol, bool live,
+                                              int thr, int* cnt, uint64_t* cand_base) {
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 31; t >= 0; --t)
+        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(acc[t >> 2][J][t & 3]), "v"(thr) : "vcc");
+    if (partial) {                                  // last tile of the index: rows past the end are not rows
+        const int left = (int)min((int64_t)SCAN_BM, max((int64_t)0, n_rows - row_base));
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = min(4, max(0, left - i * 16));
+            valid |= ((1u << n) - 1u) << (i * 4);
+        }
+        m &= valid;
+    }
+    if (!live) m = 0;
+    unsigned todo = wave_or_u32(m);
+    if (todo == 0) return;
+    const int mine = __popc(m);
+    int slot = 0;
+    if (mine) slot = atomicAdd(&cnt[qcol], mine);
+    uint64_t* list = cand_base + (size_t)qcol * CAND_CAP;
+    while (todo) {
+        const int t = __builtin_ctz(todo);          // uniform
+        todo &= todo - 1;
+        const int sc = pick_acc_i32<J>(acc, t);
+        if (m & (1u << t)) {
+            const int64_t row = row_base + (t >> 2) * 16 + (t & 3);
+            if (slot < CAND_CAP) list[slot] = make_key_i32(sc, (uint32_t)row);
+            ++slot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    S8 P;
+    P.lane = lane;
+    P.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = P.wave >> 2;           // waves w and w + 4 share a SIMD
+    P.wm = P.wave >> 2;
+    P.wn = P.wave & 3;
+    P.order = (P.wave >> 1) & 1;
+    P.pend_h = -1;
+    P.pend_stage = 0;
+    P.defer_on = true;
+    P.smem = smem;
+
+    int logical = blockIdx.x;
+    const int G = gridDim.x;
+    if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
+    const int q0 = qb * BNQ;
+
+    int tile_begin, tile_end;
+    chunk_tile_range(p.n_tiles, p.n_chunks, chunk, tile_begin, tile_end);
+    P.nt = tile_end - tile_begin;
+    P.HS = p.K / 64;
+    P.J = P.nt * P.HS;
+    P.tile_bytes = p.tile_stride;
+    const size_t ldB = (size_t)p.q_pitch;
+
+    int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
+    int* flags = reinterpret_cast<int*>(smem + OFF_FLAGS);
+    for (int i = tid; i < BNQ; i += SCAN_THREADS) cnt[i] = 0;
+    if (tid < 16) flags[tid] = 0;
+    uint64_t* cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    const int q_live = min(BNQ, p.B - q0);
+
+    // ---- per-lane DMA source offsets (scan_pp.hip): piece t covers LDS lines 8t .. 8t+7; lane l writes chunk position
+    // l & 7 of line 8t + (l >> 3), which holds logical chunk c = pos ^ ((line >> 1) & 7): bytes (c & 3) * 16 of the slice of
+    // tile row line + 128 * (c >> 2).  DB rows of a half-step block are 64 B apart (tiled copy), query rows q_pitch apart.
+    {
+        const int line = P.wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((line >> 1) & 7);
+        const int row = line + 128 * (c >> 2);
+        P.offA0 = (unsigned)(row * HALF_BYTES) + (c & 3) * 16;
+        P.offB0 = (unsigned)(row * ldB) + (c & 3) * 16;
+        P.offA1 = P.offA0 + (unsigned)(64 * HALF_BYTES);
+        P.offB1 = P.offB0 + (unsigned)(64 * ldB);
+    }
+    {
+        const int r = lane & 15, cq = lane >> 4, sw = (r >> 1) & 7;
+        P.rdA = (unsigned)(r * LINE_BYTES + (((P.wm * 4 + cq) ^ sw) << 4));
+        P.rdB = (unsigned)(((P.wn & 1) * 64 + r) * LINE_BYTES + ((((P.wn >> 1) * 4 + cq) ^ sw) << 4));
+    }
+    P.qbase = reinterpret_cast<const char*>(p.q8) + (size_t)q0 * ldB;
+    P.scales_src = reinterpret_cast<const char*>(p.sxi + (size_t)tile_begin * SCAN_BM);
+    const char* tile0 = reinterpret_cast<const char*>(p.db8) + (long long)tile_begin * p.tile_stride;
+    P.rd = Cur{0, 0, tile0};
+    P.dm = Cur{0, 0, tile0};
+
+    // this lane's four collect thresholds (fixed for the whole scan) and whether its queries exist
+    int thr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) thr[c] = p.thr_int[q0 + P.wn * 64 + c * 16 + (lane & 15)];
+
+    i32x4 acc[8][4];
+    AOps a;
+    BOps b;
+
+    // ---- prologue: half-steps 0, 1, 2 (the launcher admits dim >= 256 only: HS >= 4, so J >= 4 whenever J > 0, and the
+    // row scales of tile e + 1 -- fetched three half-steps ahead -- never land in the buffer tile e is still using)
+    if (P.J > 0) {
+        for (int s = 0; s < 3 && s < P.J; ++s) {
+            P.issue(P.dm, s, true);
+            P.advance(P.dm);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's pieces (inline asm: the compiler does not wait for them)
+    __syncthreads();
+
+    if (P.J > 0) {
+        const int HS = P.HS;
+        int j = 0;
+        unsigned cols = 0;
+        int* any_cols = flags + 8;
+        auto last_phase = [&](int e) {
+            const i32x4* sc = reinterpret_cast<const i32x4*>(smem + OFF_SCALES + (e & 1) * 1024 + (P.wm * 128 + (lane >> 4) * 4) * 4);
+            cols = cmp_phase_last(acc, a, b, sc, thr);
+            if (cols != 0 && fresh_lane() == 0) *any_cols = 1;
+        };
+        // after the barrier that ends G1's last compute phase of entry e: every wave takes the same path
+        auto tile_end = [&](int e) {
+            const bool any = __builtin_amdgcn_readfirstlane(*any_cols) != 0;
+            if (!any) return;
+            if (cols) {
+                const int fl = fresh_lane();
+                const int64_t tile_row0 = (int64_t)(tile_begin + e) * SCAN_BM;
+                const int64_t row_base = tile_row0 + P.wm * 128 + (fl >> 4) * 4;
+                const bool partial = tile_row0 + SCAN_BM > p.n_rows;
+                const int qc0 = P.wn * 64 + (fl & 15);
+                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], cnt, cand_base);
+                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], cnt, cand_base);
+                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], cnt, cand_base);
+                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], cnt, cand_base);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            I8_BARRIER();
+            if (tid == 0) *any_cols = 0;       // read again a whole tile later
+        };
+        //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [append phase] | CMP(e+1,0) | MEM(e+1,1) ..
+        //     G1: .. MEM(e,last) | CMP_LAST(e)| [append phase] | MEM(e+1,0) | CMP(e+1,0) ..
+        if (group == 0) {
+            mem_phase(P, a, b, 0, false);
+            I8_BARRIER();
+            for (int e = 0; e < P.nt; ++e) {
+                cmp_phase<true>(acc, a, b);
+                I8_BARRIER();
+                mem_phase(P, a, b, j + 1, P.defer_on && HS > 2);
+                I8_BARRIER();
+                ++j;
+                for (int h = 1; h < HS - 1; ++h) {
+                    cmp_phase_mid(P, acc, a, b);
+                    I8_BARRIER();
+                    mem_phase(P, a, b, j + 1, P.defer_on && h < HS - 2);
+                    I8_BARRIER();
+                    ++j;
+                }
+                last_phase(e);
+                I8_BARRIER();
+                if (j + 1 < P.J) mem_phase(P, a, b, j + 1, false);
+                I8_BARRIER();
+                ++j;
+                tile_end(e);
+            }
+        } else {
+            I8_BARRIER();
+            for (int e = 0; e < P.nt; ++e) {
+                mem_phase(P, a, b, j, false);
+                I8_BARRIER();
+                cmp_phase<true>(acc, a, b);
+                I8_BARRIER();
+                ++j;
+                for (int h = 1; h < HS - 1; ++h) {
+                    mem_phase(P, a, b, j, P.defer_on);
+                    I8_BARRIER();
+                    cmp_phase_mid(P, acc, a, b);
+                    I8_BARRIER();
+                    ++j;
+                }
+                mem_phase(P, a, b, j, false);
+                I8_BARRIER();
+                last_phase(e);
+                I8_BARRIER();
+                ++j;
+                tile_end(e);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < BNQ; i += SCAN_THREADS) p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
+}
+
+}  // namespace
+
+int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
+    if (a.K % 64 != 0 || a.K < 256) return fail(SQE_ERR_INVALID, "int8 scan: dim must be a multiple of 64, >= 256");
+    if (a.b_pad % BNQ != 0 || a.qblocks * BNQ != a.b_pad) return fail(SQE_ERR_INVALID, "int8 scan: query block must be 256");
+    I8KernelArgs k;
+    k.db8 = a.db8; k.tile_stride = a.tile_stride; k.sxi = a.sxi; k.q8 = a.q8; k.q_pitch = a.q_pitch; k.thr_int = a.thr_int;
+    k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = a.b_pad; k.n_tiles = a.n_tiles; k.n_chunks = a.n_chunks; k.qblocks = a.qblocks;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.dbg = 0;
+    auto kern = scan_i8_pp_kernel;
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(a.n_chunks * a.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+}  // namespace sqe

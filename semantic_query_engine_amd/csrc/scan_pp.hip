@@ -163,7 +163,7 @@ struct PP {
     int wave, wm, wn;
     bool tile_skew;                        // knobs build, SQE_DBG bit 8192: tiles start (tile % 16) * 2 KiB into their footprint
     int h_stride;                          // bytes between the 32-wide K slices of a DB tile row (64; knobs build: see SQE_DBG bit 8192)
-    int tile_begin, nt, HS, J;
+    int tile_begin, nt, HS, J, tile_step;
     long long tile_bytes;
     int kp, trig, gshift, gshift_k, k_rows, refresh_mask;   // refresh_mask + 1: half-steps between bound fetches early in a chunk (power of two)
     int e_fast, e_mid, late_mask;          // bound-table fetch schedule (kernel start)
@@ -188,7 +188,7 @@ struct PP {
         }
     }
     __device__ __forceinline__ int64_t row0_of(int e) const {
-        return (int64_t)(e < nt ? tile_begin + e : tile_begin) * SCAN_BM;
+        return (int64_t)(e < nt ? tile_begin + e : tile_begin) * tile_step * SCAN_BM;
     }
     // this wave's four 1-KiB pieces of a half-step: DB pieces wave, wave + 8; query pieces likewise
     __device__ __forceinline__ void issue_a(const Cursor& c, int stage) const {
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     const int n_entries = P.nt > 0 ? P.nt + 1 : 0;
     P.J = n_entries * P.HS;
     const size_t ldA = (size_t)p.db_pitch, ldB = (size_t)p.q_pitch;
-    P.tile_bytes = (long long)SCAN_BM * (long long)ldA;
+    P.tile_step = p.tile_step;
+    P.tile_bytes = (long long)SCAN_BM * (long long)ldA * p.tile_step;
     {
         // bound-table fetches: every slice per tile for the first e_fast tiles of a chunk, one slice per tile up to e_mid,
         // then one slice every (late_mask + 1)-th tile.  A fetch costs ~2,500 cycles of the workgroup (16 KiB of DMA, two
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
         P.rdB = (unsigned)(((P.wn & 1) * 64 + r) * LINE_BYTES + ((((P.wn >> 1) * 4 + cq) ^ sw) << 4));
     }
     P.qbase = reinterpret_cast<const char*>(p.q) + (size_t)q0 * ldB;
-    const char* tile0 = reinterpret_cast<const char*>(p.db) + (size_t)P.tile_begin * SCAN_BM * ldA;
+    const char* tile0 = reinterpret_cast<const char*>(p.db) + (size_t)P.tile_begin * p.tile_step * SCAN_BM * ldA;
     P.rd = Cursor{0, 0, tile0};
     P.dm = Cursor{0, 0, tile0};
     P.refresh_pending = -1;
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
 
     // ---- tail: filter of the last entry (the rescan of the first tile)
     if (P.J > 0 && !P.no_filter) {
-        if (filter_tile<8, 4>(acc, f, (int64_t)P.tile_begin * SCAN_BM, P.wm * 128, P.wn * 64, lane))
+        if (filter_tile<8, 4>(acc, f, P.row0_of(0), P.wm * 128, P.wn * 64, lane))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();

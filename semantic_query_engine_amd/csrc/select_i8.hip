@@ -1,0 +1,201 @@
+// select_i8.hip -- after the int8 collect scan (scan_i8.hip): per query, gather the collected keys, re-score in fp32 what can
+// matter, select the exact top-k and prove that no uncollected row can belong to it.  One workgroup per query.
+//
+//   keys   (int8 score, row) of every row whose scaled int8 score reached the query's threshold, from the (chunk, query)
+//          lists; sorted best first in LDS (bitonic, <= 4096 keys);
+//   stage 1  the 64 best by int8 score are re-scored against the fp32 master: t1 = k-th best TRUE cosine among them, a
+//          lower bound of the final k-th cosine;
+//   stage 2  a row whose estimated score is below t1 - eps has a true cosine below t1: it cannot enter the top-k.  Every
+//          other collected row -- a prefix of the sorted keys -- is re-scored too (~300 rows per query on 10 M Gaussian rows
+//          against ~1,600 collected: the re-score reads 4 KiB per row, the collection 8 bytes);
+//   result  the k best of the re-scored rows by (cosine desc, row asc), exact fp32 cosines;
+//   proof   an uncollected row has an estimated score below thr_eff (scan_i8.hip), hence a true cosine below
+//          thr_eff + eps; the query is certified when that is below the k-th cosine found, and no list or buffer overflowed.
+//          eps = scan_eps(int8 residual of the query, largest int8 residual of the index): kernels.h, the same bound the
+//          bf16 certificate uses with the bf16 residuals.
+//   else   collect_thr[q] = (k-th cosine found) - bf16 eps: the query joins the bf16 collect pass (exact.hip), which
+//          gathers every row that can still reach that cosine and overwrites the result.
+#include "kernels.h"
+
+namespace sqe {
+
+namespace {
+
+constexpr int KEY_CAP = 4096;      // collected keys per query held in LDS
+constexpr int RS_CAP = 2048;       // rows re-scored per query
+constexpr int STAGE1 = 64;
+
+struct SelArgs {
+    I8SelectArgs a;
+    float unit0;                   // S0^2
+};
+
+// descending bitonic sort of n (power of two) keys in LDS, all threads of the block
+__device__ __forceinline__ void bitonic_desc(uint64_t* v, int n) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (n >> 1); t += nt) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t x = v[lo], y = v[hi];
+                if ((x < y) == desc) { v[lo] = y; v[hi] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int key_score_i32(uint64_t key) { return (int)((uint32_t)(key >> 32) ^ 0x80000000u); }
+
+// true cosines of rows keys[lo .. hi) -> tk[lo .. hi) as (cosine, row) keys; one wave per row, two rows in flight
+__device__ __forceinline__ void rescore_range(const uint64_t* keys, uint64_t* tk, int lo, int hi, const float* master, const float* qrow, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nvec = K >> 2;
+    const float4* qv = reinterpret_cast<const float4*>(qrow);
+    for (int e = lo + wave * 2; e < hi; e += nw * 2) {
+        const uint32_t r0 = key_row(keys[e]);
+        const bool two = e + 1 < hi;
+        const uint32_t r1 = two ? key_row(keys[e + 1]) : r0;
+        const float4* a0 = reinterpret_cast<const float4*>(master + (size_t)r0 * K);
+        const float4* a1 = reinterpret_cast<const float4*>(master + (size_t)r1 * K);
+        float s0 = 0.f, s1 = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            const float4 x0 = a0[v], x1 = a1[v], b = qv[v];
+            s0 = fmaf(x0.x, b.x, s0); s0 = fmaf(x0.y, b.y, s0); s0 = fmaf(x0.z, b.z, s0); s0 = fmaf(x0.w, b.w, s0);
+            s1 = fmaf(x1.x, b.x, s1); s1 = fmaf(x1.y, b.y, s1); s1 = fmaf(x1.z, b.z, s1); s1 = fmaf(x1.w, b.w, s1);
+        }
+        s0 = wave_sum(s0) + 0.0f;
+        s1 = wave_sum(s1) + 0.0f;
+        if (lane == 0) {
+            tk[e] = make_key(s0, r0);
+            if (two) tk[e + 1] = make_key(s1, r1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void select_i8_kernel(SelArgs sa) {
+    const I8SelectArgs& p = sa.a;
+    __shared__ uint64_t keys[KEY_CAP];
+    __shared__ uint64_t tk[RS_CAP];
+    __shared__ int s_total, s_over, s_cut;
+    __shared__ uint64_t s_t1;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_total = 0; s_over = 0; s_cut = 0; s_t1 = 0ull; }
+    __syncthreads();
+    // ---- gather: one wave per chunk list
+    for (int c = wave; c < p.n_chunks; c += 8) {
+        int n = p.cand_cnt[(size_t)c * p.b_pad + q];
+        if (n > CAND_CAP) { n = CAND_CAP; if (lane == 0) s_over = 1; }       // the list overflowed: rows were dropped
+        if (n <= 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_total, n);
+        base = __shfl(base, 0, 64);
+        const uint64_t* list = p.cand + ((size_t)c * p.b_pad + q) * CAND_CAP;
+        for (int i = lane; i < n; i += 64)
+            if (base + i < KEY_CAP) keys[base + i] = list[i];
+    }
+    __syncthreads();
+    int N = s_total;
+    bool overflow = s_over != 0;
+    if (N > KEY_CAP) { N = KEY_CAP; overflow = true; }
+    int np2 = 1;
+    while (np2 < N) np2 <<= 1;
+    for (int i = N + tid; i < np2; i += blockDim.x) keys[i] = 0ull;           // key 0 sorts last (a real key is never 0)
+    bitonic_desc(keys, np2);
+    // ---- stage 1
+    const float* qrow = p.qn + (size_t)q * p.K;
+    const int R1 = min(N, STAGE1);
+    rescore_range(keys, tk, 0, R1, p.master, qrow, p.K);
+    __syncthreads();
+    if (tid < R1) {                                                           // k-th largest of the first R1 true keys by rank counting
+        const uint64_t me = tk[tid];
+        int rank = 0;
+        for (int j = 0; j < R1; ++j) rank += tk[j] > me ? 1 : 0;
+        if (rank == p.k - 1) s_t1 = me;
+    }
+    __syncthreads();
+    const float eps8 = scan_eps(p.q_resid8[q], __uint_as_float(*p.db_resid8_max), p.K);
+    const double unit = (double)sa.unit0 * (double)p.sqi[q];
+    int R2 = N;                                                               // fewer than k rows in stage 1: everything is re-scored
+    if (R1 >= p.k && N > R1) {
+        const float t1 = key_score(s_t1);
+        // rows with score_int < thr2 have an estimated cosine below t1 - eps8, a true cosine below t1
+        const double v = floor(((double)t1 - (double)eps8) / unit) - 1.0;
+        const int thr2 = v < -2.0e9 ? -0x7fffffff : v > 2.0e9 ? 0x7fffffff : (int)v;
+        // keys are sorted by score: the cut is the first position whose score is below thr2
+        for (int i = tid; i < N; i += blockDim.x) {
+            const bool below = key_score_i32(keys[i]) < thr2;
+            const bool prev_below = i > 0 && key_score_i32(keys[i - 1]) < thr2;
+            if (below && !prev_below) s_cut = i + 1;                          // + 1: 0 means "no position is below"
+        }
+        __syncthreads();
+        R2 = s_cut > 0 ? s_cut - 1 : N;
+        if (R2 < R1) R2 = R1;
+    }
+    if (R2 > RS_CAP) { R2 = RS_CAP; overflow = true; }
+    rescore_range(keys, tk, R1, R2, p.master, qrow, p.K);
+    __syncthreads();
+    // ---- final order of the re-scored rows
+    int rp2 = 1;
+    while (rp2 < R2) rp2 <<= 1;
+    for (int i = R2 + tid; i < rp2; i += blockDim.x) tk[i] = 0ull;
+    bitonic_desc(tk, rp2);
+    const int m = min(R2, p.k);
+    float* cos_out = p.cos_out + (size_t)q * p.k;
+    int64_t* id_out = p.id_out + (size_t)q * p.k;
+    // Fewer than k rows collected (the threshold sat inside a band of near-identical rows and the int8 estimates fell
+    // on the wrong side of it): the k best rows of the SAMPLE -- real rows with true cosines -- stand in until the bf16
+    // pass, which this query now takes, overwrites them.
+    const bool from_sample = m < p.k;
+    const float* cs = p.sample_cos + (size_t)q * p.sample_m;
+    const int64_t* is = p.sample_ids + (size_t)q * p.sample_m;
+    for (int i = tid; i < p.k; i += blockDim.x) {
+        if (from_sample) {
+            cos_out[i] = cs[i];
+            id_out[i] = is[i] >= 0 ? is[i] + p.id_base : -1;
+        } else {
+            cos_out[i] = key_score(tk[i]);
+            id_out[i] = (int64_t)key_row(tk[i]) + p.id_base;
+        }
+    }
+    if (tid == 0) {
+        const float kth = m >= p.k ? key_score(tk[p.k - 1]) : -INFINITY;
+        const bool certified = !overflow && m >= p.k && p.thr_eff[q] + eps8 < kth;
+        float thr = INFINITY;
+        if (!certified) {
+            const float eps16 = scan_eps(p.q_resid16[q], __uint_as_float(*p.db_resid16_max), p.K);
+            // lower bounds of the true k-th cosine: the k-th found here, the k-th of the sample (both are real rows)
+            const float lb = fmaxf(kth, cs[p.k - 1]);
+            thr = (lb > -INFINITY ? lb : -1.0f) - eps16;
+            atomicAdd(p.unc_count, 1);
+        }
+        p.collect_thr[q] = thr;
+        if (p.stats) {
+            atomicAdd(&p.stats[0], (unsigned long long)N);
+            atomicAdd(&p.stats[1], (unsigned long long)R2);
+            if (overflow) atomicAdd(&p.stats[2], 1ull);
+            if (!certified) atomicAdd(&p.stats[3], 1ull);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_select_i8(const I8SelectArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return SQE_OK;
+    if (a.k < 1 || a.k > STAGE1 || a.k > a.sample_m) return fail(SQE_ERR_INVALID, "int8 select: k must be in [1, min(64, sample depth)]");
+    if (a.K % 4 != 0) return fail(SQE_ERR_INVALID, "int8 select: dim must be a multiple of 4");
+    SelArgs sa;
+    sa.a = a;
+    const float s0 = i8_scale_unit(a.K);
+    sa.unit0 = s0 * s0;
+    hipLaunchKernelGGL(select_i8_kernel, dim3(a.B), dim3(512), 0, stream, sa);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+}  // namespace sqe

@@ -17,7 +17,7 @@ from . import _native as N
 INDEX_FLAT = 0
 INDEX_IVF_FLAT = 1
 SCAN_BF16_RESCORE = 0
-SCAN_FP32 = 1
+SCAN_INT8_RESCORE = 2
 
 
 def _f32(a: np.ndarray) -> np.ndarray:

@@ -42,7 +42,7 @@ def test_version_and_error_string(lib):
 def test_struct_layouts_match_header():
     from semantic_query_engine_amd import _native
     assert ctypes.sizeof(_native.BertCfg) == 32
-    assert ctypes.sizeof(_native.Stats) == 6 * 8 + 6 * 8
+    assert ctypes.sizeof(_native.Stats) == 6 * 8 + 6 * 8 + 4 * 8      # + sample_ms and the three int8 counters (r03)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -1,0 +1,210 @@
+"""The int8 first-pass scan (scan_mode = SQE_SCAN_INT8_RESCORE: quant.hip, scan_i8.hip, select_i8.hip) against the exact
+oracle.  Whatever the int8 rounding does, the answer must be the exact fp32 top-k: ids bit-exact (rows closer than fp32
+resolves may swap), cosines within 1e-3 (north_star) -- measured ~1e-7, they are fp32 re-scores.  The cases cover what is
+new in this path: the sample-derived thresholds (good, too high, too low), the per-row scales (rows with one huge
+element, zero rows), list overflow and certificate failure (-> the bf16 collect pass), a partial last tile, lazy
+quantisation across appends and index growth, overwritten rows.  GPU only."""
+import numpy as np
+import pytest
+
+from oracle import retrieval as R
+from tests.gpu_util import assert_topk_matches, exact_topk_fast
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from semantic_query_engine_amd import Context
+    return Context(0)
+
+
+def _i8_index(ctx, dim, step=8, m=32, min_rows=0):
+    from semantic_query_engine_amd import SCAN_INT8_RESCORE, VectorIndex
+    idx = VectorIndex(ctx, dim)
+    idx.set_option("scan_mode", SCAN_INT8_RESCORE)
+    idx.set_option("i8_min_rows", min_rows)
+    idx.set_option("i8_sample_step", step)
+    idx.set_option("i8_sample_m", m)
+    return idx
+
+
+def _check(ctx, idx, x, q, k, want_i8=True, **kw):
+    ctx.stats_reset()
+    cos, ids = idx.search(q, k)
+    st = ctx.stats()
+    ref_cos, ref_ids = exact_topk_fast(x, q, k)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q), **kw)
+    assert np.abs(cos - ref_cos)[ref_ids >= 0].max() < 1e-5
+    if want_i8:
+        assert st["i8_collected"] > 0 and st["sample_ms"] >= 0.0      # the int8 path answered (not the bf16 scan)
+    return cos, ids, st
+
+
+@pytest.mark.parametrize("n,d,b,k,unc_max", [(300_000, 1024, 300, 10, 0.02), (120_001, 256, 1024, 10, 0.02), (70_000, 512, 129, 1, 0.02),
+                                             (100_000, 1024, 700, 32, 0.5)])
+def test_gaussian_rows_exact_and_certified(ctx, n, d, b, k, unc_max):
+    """Sample every 8th tile, threshold = 64th best cosine of the sample (~512 rows collected per query): at these index
+    sizes the 10th -> 512th gap is ~1 sigma against an int8 bound of ~0.75 sigma (the 10 M-row defaults, every 50th tile
+    and the 32nd best, leave 1.15 sigma); with k = 32 the gap is thinner than the bound for many queries, which then
+    take the bf16 pass -- the answers are exact either way."""
+    rng = np.random.default_rng(n + b)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    plant = rng.integers(0, n, b // 2)
+    q[: b // 2] = x[plant] + 0.1 * q[: b // 2]
+    idx = _i8_index(ctx, d, step=8, m=64)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k)
+    assert np.array_equal(ids[: b // 2, 0], plant)
+    assert st["i8_overflows"] == 0
+    assert st["uncertified"] <= max(1, int(b * unc_max)), st         # the int8 certificate holds for (almost) every query
+    assert st["i8_rescored"] <= st["i8_collected"]
+    # small batches and k beyond the sample depth take the bf16 scan -- same answers
+    c1, i1 = idx.search(q[:7], k)
+    assert np.array_equal(i1, ids[:7]) and np.allclose(c1, cos[:7], atol=2e-6)
+    idx.close()
+
+
+def test_near_ties_at_the_kth_place(ctx):
+    """40 planted rows per query whose true cosines differ by 1e-5 -- the int8 scores (noise ~1e-3) scramble them
+    completely; the staged re-score must still return the exact order."""
+    rng = np.random.default_rng(17)
+    d, n, b, k, planted = 256, 60000, 200, 10, 40
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    qn = R.normalize_rows(q).astype(np.float64)
+    rows = rng.permutation(n)[:b * planted].reshape(b, planted)
+    for i in range(b):
+        noise = rng.standard_normal((planted, d))
+        noise -= (noise @ qn[i])[:, None] * qn[i][None, :]
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        c = 0.6 - 1e-5 * rng.permutation(planted)
+        x[rows[i]] = (c[:, None] * qn[i][None, :] + np.sqrt(1 - c * c)[:, None] * noise).astype(np.float32)
+    idx = _i8_index(ctx, d, step=4)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k)
+    assert all(set(ids[i].tolist()) <= set(rows[i].tolist()) for i in range(b))
+    idx.close()
+
+
+def test_clustered_rows_fall_back_and_stay_exact(ctx):
+    """Tightly clustered rows: thousands of rows sit inside the int8 error band of the k-th place, the certificate
+    fails (or the lists overflow) and the bf16 collect pass answers.  Still the exact top-k."""
+    rng = np.random.default_rng(23)
+    d, n, b, k = 256, 80000, 300, 10
+    cen = rng.standard_normal((40, d)).astype(np.float32)
+    x = (cen[rng.integers(0, 40, n)] + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (cen[rng.integers(0, 40, b)] + 0.05 * rng.standard_normal((b, d))).astype(np.float32)
+    idx = _i8_index(ctx, d, step=4)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k, tol=5e-6)
+    assert st["uncertified"] > 0                             # this data is what the fallback is for
+    idx.close()
+
+
+@pytest.mark.parametrize("step,m", [(64, 1), (1, 64)])
+def test_thresholds_too_high_or_too_low(ctx, step, m):
+    """(64, 1): the threshold is the BEST cosine of a 1.5 % sample -- far above the 10th best of the index, the proof
+    fails for most queries.  (1, 64): every tile is in the sample and the threshold is the 64th best of the index itself
+    -- few rows collected, proof margin thin.  Both must return the exact answer."""
+    rng = np.random.default_rng(31 + step)
+    d, n, b, k = 512, 150_000, 260, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    idx = _i8_index(ctx, d, step=step, m=max(m, k))
+    idx.add(x)
+    _check(ctx, idx, x, q, k)
+    idx.close()
+
+
+def test_rows_with_outlier_elements_zero_rows_and_partial_tile(ctx):
+    """Per-row scales: rows dominated by ONE element (scale 8 x the typical one), all-zero rows (main.py:315-316 keeps
+    them zero), rows scaled by 1e-20 / 1e+20 before normalisation; n is not a multiple of the 256-row tile."""
+    rng = np.random.default_rng(41)
+    d, n, b, k = 256, 50_003, 256, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    spikes = rng.permutation(n)[:500]
+    x[spikes, rng.integers(0, d, 500)] += 40.0                # cosine ~0.93 with the axis
+    x[rng.permutation(n)[:50]] = 0.0
+    x[100:110] *= 1e-20
+    x[200:210] *= 1e+18
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    q[:64] = x[spikes[:64]] + 0.5 * q[:64]                    # queries whose neighbours are spike rows
+    q[64:70] = x[200:206] * 1e-10                             # neighbours among the huge rows (the tiny ones normalise to ~0: 1e-9 rule)
+    idx = _i8_index(ctx, d, step=4)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k)
+    assert np.array_equal(ids[:64, 0], spikes[:64])
+    assert np.array_equal(ids[64:70, 0], np.arange(200, 206))
+    idx.close()
+
+
+def test_appends_growth_and_overwrites(ctx):
+    """The int8 copy is filled lazily by the first search after an add and follows index growth and row overwrites."""
+    rng = np.random.default_rng(53)
+    d, b, k = 256, 300, 5
+    x = rng.standard_normal((90_000, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    idx = _i8_index(ctx, d, step=4)
+    idx.add(x[:20_000])
+    _check(ctx, idx, x[:20_000], q, k)
+    idx.add(x[20_000:20_001])                                 # one row: lands in a tile that is already quantised
+    idx.add(x[20_001:61_234])                                 # grows the index (new buffers), partial tiles on both ends
+    _check(ctx, idx, x[:61_234], q, k)
+    idx.add(x[61_234:])
+    upd = np.array([3, 19_999, 20_000, 61_233, 89_999])
+    x[upd] = q[:5] * 2.0
+    idx.update(upd, x[upd])
+    cos, ids, st = _check(ctx, idx, x, q, k)
+    assert ids[:5, 0].tolist() == upd.tolist() and np.all(cos[:5, 0] > 0.999999)
+    idx.close()
+
+
+def test_full_size_properties_int8():
+    """BASELINE size (10 M x 1024, batch 1024, top-10) in int8 mode, through what the oracle cannot check directly:
+    planted neighbours first, and the whole result EQUAL to the bf16-mode result of the same index (both are exact)."""
+    import torch
+    from semantic_query_engine_amd import SCAN_BF16_RESCORE, SCAN_INT8_RESCORE, Context, VectorIndex
+    from tests.test_fullsize_gpu import BLOCK, D, K, N, _block
+    dev = torch.device("cuda", 0)
+    ctx = Context(0)
+    idx = VectorIndex(ctx, D)
+    idx.reserve(N)
+    nblocks = (N + BLOCK - 1) // BLOCK
+    for blk in range(nblocks):
+        rows = min(BLOCK, N - blk * BLOCK)
+        xb = _block(blk, rows, dev)
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), rows)
+        ctx.synchronize()
+        del xb
+    B = 1024
+    g = torch.Generator(device=dev).manual_seed(11)
+    q = torch.randn((B, D), generator=g, device=dev)
+    plant = torch.arange(B // 2, device=dev) * (N // B) + 5
+    for blk in range(nblocks):
+        lo, hi = blk * BLOCK, min(N, (blk + 1) * BLOCK)
+        sel = torch.nonzero((plant >= lo) & (plant < hi)).flatten()
+        if sel.numel():
+            xb = _block(blk, hi - lo, dev)
+            q[sel] = xb[plant[sel] - lo] * 1.3 + 0.2 * q[sel]
+            del xb
+    out = {}
+    for mode in (SCAN_BF16_RESCORE, SCAN_INT8_RESCORE):
+        idx.set_option("scan_mode", mode)
+        cos = torch.empty((B, K), device=dev)
+        ids = torch.empty((B, K), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ctx.stats_reset()
+        idx.search_device(q.data_ptr(), B, K, cos.data_ptr(), ids.data_ptr())
+        ctx.synchronize()
+        out[mode] = (cos.cpu(), ids.cpu(), ctx.stats())
+    c16, i16, s16 = out[SCAN_BF16_RESCORE]
+    c8, i8, s8 = out[SCAN_INT8_RESCORE]
+    assert s8["i8_collected"] > 0 and s16["i8_collected"] == 0
+    assert torch.equal(i8[: B // 2, 0], plant.cpu())
+    assert torch.equal(i8, i16) and torch.allclose(c8, c16, atol=2e-6)
+    assert s8["uncertified"] <= 4 and s8["i8_overflows"] == 0, s8
+    # the re-score reads a few hundred rows per query, the collection a couple of thousand keys
+    assert s8["i8_rescored"] < 1024 * 1200 and s8["i8_collected"] < 1024 * 4000, s8
