@@ -78,31 +78,34 @@ def library_gemm_tflops(b: int, device) -> float:
     return 2.0 * b * n * D / ms / 1e9
 
 
-def scan_source_hash() -> str:
-    """sha256 over the sources of the scan kernels: a PMC traffic figure is only quoted for the kernel it was
+def scan_source_hash(mode: str = "bf16") -> str:
+    """sha256 over the sources of the scan kernels of `mode`: a PMC traffic figure is only quoted for the kernel it was
     measured on (tools/pmc_scan.sh records the same hash next to the bytes)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "semantic_query_engine_amd", "csrc")
-    for name in ("common.h", "kernels.h", "scan_common.h", "scan.hip", "scan_pp.hip"):
+    names = ("common.h", "kernels.h", "scan_common.h", "scan.hip", "scan_pp.hip")
+    if mode == "int8":
+        names = ("common.h", "kernels.h", "scan_common.h", "scan_i8.hip", "quant.hip")
+    for name in names:
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def committed_traffic(rows: int, b: int):
+def committed_traffic(rows: int, b: int, mode: str = "bf16"):
     """(HBM bytes per scan launch, source file) from the committed rocprofv3 PMC passes (tools/pmc_scan.sh ->
     profiles/r*/pmc_traffic*.json) taken on this workload AND on the scan kernel sources of this tree;
     (None, reason) otherwise.  The figure is read from a committed file, not measured in this run."""
     import glob
-    want = scan_source_hash()
+    want = scan_source_hash(mode)
     stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")), reverse=True):
         try:
             t = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if t.get("rows") == rows and t.get("batch") == b:
+        if t.get("rows") == rows and t.get("batch") == b and t.get("scan_mode", "bf16") == mode:
             rel = os.path.relpath(path, ROOT)
             if t.get("scan_src_sha") == want:
                 return float(t["hbm_bytes_per_launch"]), rel
@@ -265,8 +268,11 @@ def main():
                          "N x as large (e.g. 10000000 -> 80M rows on 8 GPUs); overrides --rows")
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--scan-mode", choices=["bf16", "int8"], default="bf16",
-                    help="first-pass scan type (sqe.h: SQE_SCAN_*); both return the exact fp32 top-k behind a certificate")
+    ap.add_argument("--scan-mode", choices=["bf16", "int8"], default="int8",
+                    help="first-pass scan type of the headline leg (sqe.h: SQE_SCAN_*); both return the exact fp32 top-k behind a "
+                         "certificate.  With int8 (the default) a second, bf16 leg of the same K steps is timed afterwards and "
+                         "reported beside it (`bf16_scan`); --no-second-leg skips it")
+    ap.add_argument("--no-second-leg", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--cpu-hnsw-rows", type=int, default=50_000,
@@ -327,10 +333,6 @@ def main():
         del x, xs
     assert len(idx) == row_hi - row_lo
     torch.cuda.empty_cache()
-    int8 = args.scan_mode == "int8"
-    if int8:
-        from semantic_query_engine_amd import SCAN_INT8_RESCORE
-        idx.set_option("scan_mode", SCAN_INT8_RESCORE)
 
     q = make_queries(b, device)
     # plant true neighbours for half the queries so recall is non-trivial
@@ -347,32 +349,37 @@ def main():
 
     searcher = ShardedSearcher(ctx, idx, id_base=row_lo, dist=dist, world=world, device=device,
                                force_collective=args.force_collective)
+    from semantic_query_engine_amd import SCAN_BF16_RESCORE, SCAN_INT8_RESCORE
 
     def step():
         return searcher.search(q, k)
 
-    for _ in range(args.warmup):
-        step()
-    searcher.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ctx.stats_reset()
-    ctx.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cos, ids = step()
-    searcher.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_leg(mode: str):
+        """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize, max over ranks."""
+        idx.set_option("scan_mode", SCAN_INT8_RESCORE if mode == "int8" else SCAN_BF16_RESCORE)
+        for _ in range(args.warmup):
+            step()
+        searcher.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.stats_reset()
+        ctx.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cos, ids = step()
+        searcher.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        if dist is not None:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, st, cos, ids
 
     # ---- correctness of what was timed: recall@k vs an independent exact scan
     nq = min(args.recall_queries, b)
@@ -386,23 +393,22 @@ def main():
         s_all, i_all = torch.cat(gs, 1), torch.cat(gi, 1)
         top = torch.topk(s_all, k, dim=1)
         ref_s, ref_i = top.values, torch.gather(i_all, 1, top.indices)
-    got_i = ids[probe]
-    got_s = cos[probe]
-    hits = sum(len(set(a.tolist()) & set(r.tolist())) for a, r in zip(got_i.cpu(), ref_i.cpu()))
-    recall = hits / (nq * k)
-    max_dcos = float((got_s - ref_s).abs().max().item())
-    planted_ok = bool((ids[: b // 2, 0] == plant_rows).all().item())
 
-    if rank == 0:
+    def check(cos, ids):
+        got_i, got_s = ids[probe], cos[probe]
+        hits = sum(len(set(a.tolist()) & set(r.tolist())) for a, r in zip(got_i.cpu(), ref_i.cpu()))
+        return {"recall_at_10": round(hits / (nq * k), 4), "max_abs_dcos": float((got_s - ref_s).abs().max().item()),
+                "planted_top1_ok": bool((ids[: b // 2, 0] == plant_rows).all().item())}
+
+    def describe(mode: str, elapsed: float, st: dict) -> dict:
+        """queries/s, stage times and the roofline object of the leg's dominant kernel (the scan)."""
+        used_i8 = mode == "int8" and st.get("i8_collected", 0) > 0
         ms_per_step = elapsed / args.steps * 1e3
-        qps = b * args.steps / elapsed
         scan_ms = st["scan_ms"] / max(st["scan_calls"], 1)
-        flops = float(st["scan_flops"])
-        bytes_ = float(st["scan_bytes"])
+        flops, bytes_ = float(st["scan_flops"]), float(st["scan_bytes"])
         tflops = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
         gbps = bytes_ / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         # binding roof: the scan needs max(flops/peak_mfma, bytes/peak_hbm) at best
-        used_i8 = int8 and st.get("i8_collected", 0) > 0
         peak_mfma = PEAK_I8_TOPS if used_i8 else PEAK_BF16_TFLOPS
         t_mfma, t_hbm = flops / (peak_mfma * 1e12), bytes_ / (PEAK_HBM_GBPS * 1e9)
         if t_mfma >= t_hbm:
@@ -411,34 +417,68 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None}
-        roof.update({"kernel": "scan_i8_pp_kernel" if used_i8 else "scan_bf16_pp_kernel" if b > 128 else "scan_bf16_kernel", "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
+        kernel = ("scan_i8_pp_kernel" if b > 128 else "scan_i8_small_kernel") if used_i8 else \
+                 ("scan_bf16_pp_kernel" if b > 128 else "scan_bf16_kernel")
+        roof.update({"kernel": kernel, "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                      "hbm_gbps": round(gbps, 1), "mfma_tflops": round(tflops, 2)})
-        if world == 1 and not used_i8:
-            roof["traffic"], roof["traffic_source"] = committed_traffic(n_total, b)
-        if roof["bound"] == "mfma" and world == 1 and not args.no_gemm_ref and not used_i8:
+        if world == 1:
+            roof["traffic"], roof["traffic_source"] = committed_traffic(n_total, b, "int8" if used_i8 else "bf16")
+        stage = {"prep": round(st["prep_ms"] / args.steps, 4), "scan": round(scan_ms, 4),
+                 "select_rescore": round(st["select_ms"] / args.steps, 4)}
+        extra = {}
+        if used_i8:
+            stage["threshold_pass"] = round(st["sample_ms"] / args.steps, 4)
+            extra["int8_last_step"] = {"keys_collected": int(st["i8_collected"]), "rows_rescored": int(st["i8_rescored"]),
+                                       "overflows": int(st["i8_overflows"])}
+        return {"used_i8": used_i8, "value": round(b * args.steps / elapsed, 1), "ms_per_step": round(ms_per_step, 4),
+                "dtype": "i8" if used_i8 else "bf16", "stage_ms": stage, "roofline": roof,
+                "uncertified_queries_last_step": int(st.get("uncertified", 0)), **extra}
+
+    elapsed, st, cos, ids = timed_leg(args.scan_mode)
+    head_check = check(cos, ids)
+    second = None
+    if args.scan_mode == "int8" and not args.no_second_leg:
+        e2, st2, cos2, ids2 = timed_leg("bf16")
+        second = (e2, st2, check(cos2, ids2), bool(torch.equal(ids2, ids)), float((cos2 - cos).abs().max().item()))
+
+    if rank == 0:
+        head = describe(args.scan_mode, elapsed, st)
+        roof = head["roofline"]
+        if roof["bound"] == "mfma" and world == 1 and not args.no_gemm_ref and not head["used_i8"]:
             lib = library_gemm_tflops(b, device)
             roof["library_gemm_tflops"] = round(lib, 1)
-            roof["frac_of_library_gemm"] = round(tflops / lib, 4)
+            roof["frac_of_library_gemm"] = round(roof["mfma_tflops"] / lib, 4)
+        first_pass = "int8 collect scan (per-row-scaled int8 copy, sample-derived thresholds)" if head["used_i8"] else "bf16 scan with fused top-k filter"
         out = {
             "metric": f"k-NN queries/sec (brute-force cosine top-{k}, 1024-d, "
                       f"{n_total // 1_000_000}M vectors)" if n_total % 1_000_000 == 0 else
                       f"k-NN queries/sec (brute-force cosine top-{k}, 1024-d, {n_total} vectors)",
-            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if args.rows_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "i8" if used_i8 else "bf16", "data": "synthetic",
-            "config": {"workload": f"flat cosine top-{k}, N={n_total} x {D} fp32 ({'int8 collect scan' if used_i8 else 'bf16 scan'} + fp32 rescore, certified exact), "
+            "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak" if args.rows_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": {"workload": f"flat cosine top-{k}, N={n_total} x {D} fp32 ({first_pass} + fp32 re-score of the candidates, "
+                                   f"exactness certified per query, bf16 collect pass for uncertified queries), "
                                    f"batch={b} queries/step, index row-sharded over {world} GPU(s)",
-                       "rows": n_total, "dim": D, "batch": b, "k": k, "parallelism": f"shard{world}"},
-            "recall_at_10": round(recall, 4), "max_abs_dcos": max_dcos, "planted_top1_ok": planted_ok,
-            "uncertified_queries_last_step": int(st.get("uncertified", 0)),
-            "stage_ms": {"prep": round(st["prep_ms"] / args.steps, 4), "scan": round(scan_ms, 4),
-                         "select_rescore": round(st["select_ms"] / args.steps, 4),
-                         **({"threshold_pass": round(st["sample_ms"] / args.steps, 4)} if used_i8 else {})},
-            **({"int8_last_step": {"keys_collected": int(st["i8_collected"]), "rows_rescored": int(st["i8_rescored"]),
-                                   "overflows": int(st["i8_overflows"])}} if used_i8 else {}),
+                       "rows": n_total, "dim": D, "batch": b, "k": k, "parallelism": f"shard{world}", "scan_mode": args.scan_mode},
+            **head_check,
+            "uncertified_queries_last_step": head["uncertified_queries_last_step"],
+            "stage_ms": head["stage_ms"],
             "roofline": roof,
         }
+        if "int8_last_step" in head:
+            out["int8_last_step"] = head["int8_last_step"]
+        if second is not None:
+            e2, st2, chk2, same_ids, dcos = second
+            leg = describe("bf16", e2, st2)
+            if leg["roofline"]["bound"] == "mfma" and world == 1 and not args.no_gemm_ref:
+                lib = library_gemm_tflops(b, device)
+                leg["roofline"]["library_gemm_tflops"] = round(lib, 1)
+                leg["roofline"]["frac_of_library_gemm"] = round(leg["roofline"]["mfma_tflops"] / lib, 4)
+            leg.pop("used_i8")
+            out["bf16_scan"] = {"note": f"second leg, same index, queries, K = {args.steps} steps after W = {args.warmup} warm-ups: the bf16 "
+                                        "first pass (scan_mode = SQE_SCAN_BF16_RESCORE); not part of `value`",
+                                **leg, **chk2, "ids_equal_to_headline_leg": same_ids, "max_abs_dcos_vs_headline_leg": dcos}
         if args.force_collective:
             out["config"]["rehearsal"] = "one-rank nccl group, all-gather + merge path forced"
         if not args.no_cpu_baseline and world == 1:

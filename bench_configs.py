@@ -259,13 +259,9 @@ def mode_ivf(args, ctx, dev):
     _, ref_ids = R.ivf_search(xn_host, R.normalize_rows(qp.cpu().numpy()), centroids, assign, k, nprobe)
     parity = float(np.mean(got == ref_ids))
     del xn_host
-    # ---- the flat scan on the same data, for the QPS comparison only
-    flat = build_clustered(ctx, args.rows, dev, centres, INDEX_FLAT, 0)
-    cf = torch.empty((b, k), device=dev); jf = torch.empty((b, k), dtype=torch.int64, device=dev)
-    flat_ms = timed(lambda: flat.search_device(q.data_ptr(), b, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
-    ivf_bytes = args.rows * D * 2                          # every list is probed at B = 1024: one read of the scan copy
-    # ---- batch sweep (r02 verdict: the reference issues B = 1, main.py:355): IVF and flat at 1 / 8 / 64 / 256 / 1024 of the
-    # same queries.  Algorithmic bytes of a point: the rows of the DISTINCT lists its queries probe (from the exported
+    # ---- batch sweep (r02 verdict: the reference issues B = 1, main.py:355): IVF at 1 / 8 / 64 / 256 / 1024 of the same
+    # queries, BEFORE the flat index is built (r03: with both 10 M-row indexes resident the same IVF searches measured
+    # 2-5 x slower).  Algorithmic bytes of a point: the rows of the DISTINCT lists its queries probe (from the exported
     # assignment and the oracle's probe order on the exported centroids) x D x 2.
     sweep = []
     cen64 = centroids.astype(np.float64)
@@ -275,14 +271,21 @@ def mode_ivf(args, ctx, dev):
         if bb > b:
             break
         t_ivf = timed(lambda: ivf.search_device(q.data_ptr(), bb, k, ci.data_ptr(), ji.data_ptr(), nprobe=nprobe), ctx.synchronize, 10)
-        t_flat = timed(lambda: flat.search_device(q.data_ptr(), bb, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
         probes = np.argsort(-(qn_all[:bb] @ cen64.T), axis=1, kind="stable")[:, :nprobe]
         rows_touched = int(list_len[np.unique(probes)].sum())
         by = rows_touched * D * 2
-        sweep.append({"batch": bb, "ivf_ms": round(t_ivf, 4), "ivf_qps": round(bb / t_ivf * 1e3), "flat_ms": round(t_flat, 4),
-                      "flat_qps": round(bb / t_flat * 1e3), "rows_in_probed_lists": rows_touched,
+        sweep.append({"batch": bb, "ivf_ms": round(t_ivf, 4), "ivf_qps": round(bb / t_ivf * 1e3), "rows_in_probed_lists": rows_touched,
                       "roofline": {"bound": "hbm", "achieved": round(by / t_ivf / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                    "frac": round(by / t_ivf / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes": by}})
+    # ---- the flat scan on the same data, for the QPS comparison only
+    flat = build_clustered(ctx, args.rows, dev, centres, INDEX_FLAT, 0)
+    cf = torch.empty((b, k), device=dev); jf = torch.empty((b, k), dtype=torch.int64, device=dev)
+    flat_ms = timed(lambda: flat.search_device(q.data_ptr(), b, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
+    ivf_bytes = args.rows * D * 2                          # every list is probed at B = 1024: one read of the scan copy
+    for pt in sweep:                                       # the flat index at the same batch sizes (every query takes the collect pass here)
+        bb = pt["batch"]
+        t_flat = timed(lambda: flat.search_device(q.data_ptr(), bb, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
+        pt["flat_ms"] = round(t_flat, 4); pt["flat_qps"] = round(bb / t_flat * 1e3)
     print(json.dumps({"mode": "ivf", "rows": args.rows, "nlist": nlist, "nprobe": nprobe, "batch": b, "train_s": round(train_s, 2),
                       "flat_ms": round(flat_ms, 3), "flat_qps": round(b / flat_ms * 1e3), "ivf_ms": round(ivf_ms, 3),
                       "ivf_qps": round(b / ivf_ms * 1e3), "probe_queries": int(probe.numel()),

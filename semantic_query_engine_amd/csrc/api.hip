@@ -559,10 +559,9 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
     float* collect_thr = certify ? reinterpret_cast<float*>(idx->unc.as<int>() + 4) : nullptr;
     // ---- int8 first pass (scan_mode INT8): threshold pass on a row sample (bf16 kernels, every step-th tile) -> fixed
     // per-query collect thresholds -> int8 collect scan over all rows -> staged fp32 re-score + certificate -> the bf16
-    // collect pass for what is left.  Batches of <= 128 queries are HBM-bound in a 64- / 128-query tile the int8 kernel
-    // does not have; small indexes give the sample nothing to estimate from: both stay with the bf16 scan.
+    // collect pass for what is left.  Small indexes give the sample nothing to estimate from: they stay with the bf16 scan.
     const int step8 = idx->i8_sample_step, m8 = idx->i8_sample_m;
-    const bool use_i8 = idx->scan_mode == SQE_SCAN_INT8_RESCORE && certify && plan.bn == 256 && K >= 256 && k <= m8 &&
+    const bool use_i8 = idx->scan_mode == SQE_SCAN_INT8_RESCORE && certify && K >= 256 && K % 128 == 0 && k <= m8 &&
                         n_rows >= idx->i8_min_rows && n_rows >= (int64_t)step8 * SCAN_BM * 4;
     if (use_i8) {
         SQE_TRY(ensure_i8_copy(idx, s));
@@ -614,7 +613,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             ia.db8 = idx->i8db.as<int8_t>(); ia.tile_stride = idx->i8_tile_stride; ia.sxi = idx->i8sxi.as<uint32_t>();
             ia.q8 = idx->q8.as<int8_t>(); ia.q_pitch = q8_pitch; ia.thr_int = idx->i8thr_int.as<int>();
             ia.n_rows = n_rows; ia.K = K; ia.B = B; ia.b_pad = plan.b_pad; ia.n_tiles = plan.n_tiles; ia.n_chunks = plan.n_chunks;
-            ia.qblocks = plan.qblocks; ia.cand = idx->cand.as<uint64_t>(); ia.cand_cnt = idx->cand_cnt.as<int>();
+            ia.qblocks = plan.qblocks; ia.bn = plan.bn; ia.cand = idx->cand.as<uint64_t>(); ia.cand_cnt = idx->cand_cnt.as<int>();
             SQE_TRY(launch_scan_i8(ia, s));
         }
         {

@@ -792,19 +792,33 @@ int launch_gemm_pp(const GemmArgs& a, int t_pad, int cu_count, hipStream_t strea
     return SQE_OK;
 }
 
-// Small-batch form: 128 x 128 tiles, 4-stage LDS ring (3 K steps of DMA in flight, counted waits, pieces
-// issued through lds_dma16 so hipcc adds no vmcnt(0) of its own), optional split-K.  With a few
-// hundred tokens a GEMM has fewer tiles than the chip has CUs and every K step of the two-stage kernel
-// above exposes a full memory round trip; here the round trips overlap and the K loop of the two
-// N = hidden GEMMs is cut into `splits` workgroups whose fp32 partial sums the LayerNorm kernels add up
-// (deterministic, no atomics).
-template <int EPI>
+// Small-batch form: LDS ring with counted waits (pieces issued through lds_dma16 so hipcc adds no vmcnt(0) of its own),
+// optional split-K.  With a few hundred to a few thousand tokens a GEMM has about as many tiles as the chip has CUs:
+// what decides its time is how many ROUNDS of tiles the grid needs and what one tile's K step costs, so the tile is
+// picked per call from a menu (r03; r02 had 128 x 128 only: at 64 x 32 tokens the QKV GEMM made 384 tiles = two
+// rounds, the second half empty, and ran at 0.46 PFLOP/s):
+//     features x tokens   stage     ring   pieces per wave
+//     (2 FM 16) x (4 FN 16)
+//      64 x  64           16 KiB     4        2
+//     128 x  64           24 KiB     4        3
+//     192 x  64           32 KiB     4        4
+//     256 x  64           40 KiB     3        5
+//     128 x 128           32 KiB     4        4        (the r02 tile)
+//     192 x 128           40 KiB     3        5
+//     256 x 128           48 KiB     3        6
+// ring_pick() takes the shape with the smallest  rounds x K steps x max(MFMA cycles, stage bytes / 28 B per cycle)
+// (a CU takes in ~55 GB/s of L2-resident operands through LDS-DMA: MI355X_MICROARCH.md, indexed rows table).  The K
+// loop of the two N = hidden GEMMs may also be cut into `splits` workgroups whose fp32 partial sums the LayerNorm
+// kernels add up (deterministic, no atomics).
+template <int EPI, int FM, int FN, int NST>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
-    constexpr int FM = 4, FN = 2, NST = 4;
     constexpr int BNW = 2 * FM * 16, BT = 4 * FN * 16;
     constexpr int STAGE = (BNW + BT) * ROWB;
-    constexpr int PIECES = (BNW / 8 + BT / 8) / 8;        // per wave per stage
-    static_assert(PIECES * (NST - 2) == 8, "counted wait below");
+    constexpr int PW = BNW / 8, PX = BT / 8;              // 1-KiB pieces (8 rows) of a stage: weights, then tokens
+    constexpr int PIECES = (PW + PX) / 8;                 // per wave per stage
+    static_assert((PW + PX) % 8 == 0, "every wave issues the same number of pieces");
+    static_assert(NST * STAGE <= 160 * 1024, "LDS budget");
+    constexpr int IN_FLIGHT = PIECES * (NST - 2);         // pieces the wait at the end of a K step leaves in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -818,21 +832,20 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
     const char* wbase = reinterpret_cast<const char*>(p.W) + (size_t)n0 * ld + (size_t)split * KS * ROWB;
     const char* xbase = reinterpret_cast<const char*>(p.X) + (size_t)t0 * ld + (size_t)split * KS * ROWB;
 
-    // per-lane source offsets of this wave's pieces (2 of W, 2 of X): rows 8*(wave + 8*i) + (lane >> 3)
-    unsigned off[2];
+    // this wave's pieces: piece q = wave + 8 i of the stage; q < PW: weight rows 8 q .., else token rows 8 (q - PW) ..
+    // (per-lane source: row 8 q' + (lane >> 3), 16-byte chunk (lane & 7) ^ swizzle(row))
+    const char* src[PIECES];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave + 8 * i) * 8 + (lane >> 3);
-        off[i] = (unsigned)(r * ld) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    for (int i = 0; i < PIECES; ++i) {
+        const int q = wave + 8 * i;
+        const bool is_w = q < PW;
+        const int r = (is_w ? q : q - PW) * 8 + (lane >> 3);
+        src[i] = (is_w ? wbase : xbase) + (size_t)r * ld + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
     auto issue = [&](int ks) {
         char* buf = smem + (ks % NST) * STAGE;
-        const char* ws = wbase + (size_t)ks * ROWB;
-        const char* xs = xbase + (size_t)ks * ROWB;
-        lds_dma16(ws + off[0], buf + wave * 1024);
-        lds_dma16(ws + off[1], buf + (wave + 8) * 1024);
-        lds_dma16(xs + off[0], buf + BNW * ROWB + wave * 1024);
-        lds_dma16(xs + off[1], buf + BNW * ROWB + (wave + 8) * 1024);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) lds_dma16(src[i] + (size_t)ks * ROWB, buf + (wave + 8 * i) * 1024);
     };
 
     f32x4 acc[FM][FN];
@@ -864,9 +877,14 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        // K step ks + 1 landed; the two younger stages stay in flight
-        if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        // K step ks + 1 landed; the younger stages stay in flight
+        if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        static_assert(IN_FLIGHT == 4 || IN_FLIGHT == 5 || IN_FLIGHT == 6 || IN_FLIGHT == 8, "a counted wait exists for this shape");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -905,26 +923,65 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
     }
 }
 
-template <int EPI>
-int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_stride, int* splits_out, hipStream_t stream) {
-    constexpr int LDS = 4 * (128 + 128) * ROWB;
-    GemmArgs p = a;
-    p.n_tiles = a.N / 128;
-    p.t_tiles = t_pad / 128;
-    const int tiles = p.n_tiles * p.t_tiles;
-    int splits = 1;
-    if (EPI == EPI_RESID) {
-        const int ks = a.K / 64;
-        while (splits < 4 && tiles * splits * 2 <= cu_count && ks % (splits * 2) == 0 && ks / (splits * 2) >= 4) splits *= 2;
-    }
-    p.splits = splits;
-    p.split_stride = split_stride;
-    if (splits_out) *splits_out = splits;
-    auto kern = gemm_ring_kernel<EPI>;
+struct RingShape { int fm, fn, nst; };
+constexpr RingShape RING_MENU[7] = {{2, 1, 4}, {4, 1, 4}, {6, 1, 4}, {8, 1, 3}, {4, 2, 4}, {6, 2, 3}, {8, 2, 3}};
+
+// estimated cycles of the whole GEMM with shape s and `splits` K slices (see the table above)
+inline double ring_cost(const RingShape& s, int N, int K, int t_pad, int splits, int cu_count) {
+    const int bnw = 2 * s.fm * 16, bt = 4 * s.fn * 16;
+    if (N % bnw != 0 || t_pad % bt != 0) return 1e30;
+    const long tiles = (long)(N / bnw) * (t_pad / bt) * splits;
+    const long rounds = (tiles + cu_count - 1) / cu_count;
+    const double mfma = s.fm * s.fn * 2 * 16.0;                       // cycles of one K step on a wave's SIMD
+    const double mem = (bnw + bt) * 128.0 / 28.0;                     // LDS-DMA intake of a CU: ~28 B per cycle
+    const double step = (mfma > mem ? mfma : mem) + 150.0;            // + barrier and issue
+    const double fill = 2500.0 + (s.nst - 1) * 0.0;                   // first stages: one memory round trip
+    return rounds * ((double)(K / 64 / splits) * step + fill + (splits > 1 ? 600.0 : 0.0));
+}
+
+template <int EPI, int FM, int FN, int NST>
+int launch_gemm_ring_shape(const GemmArgs& p, int tiles, hipStream_t stream) {
+    constexpr int LDS = NST * (2 * FM * 16 + 4 * FN * 16) * ROWB;
+    auto kern = gemm_ring_kernel<EPI, FM, FN, NST>;
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
-    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * p.splits), dim3(512), LDS, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
+}
+
+template <int EPI>
+int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_stride, int* splits_out, hipStream_t stream) {
+    GemmArgs p = a;
+    // knobs build: SQE_ENC_RING=0 pins the r02 tile (128 x 128), A/B of the shape menu
+    static const bool menu_on = [] { const char* e = knob_env("SQE_ENC_RING"); return !(e && e[0] == '0'); }();
+    int best = 4, best_splits = 1;
+    double best_cost = 1e30;
+    const int ks = a.K / 64;
+    for (int m = 0; m < 7; ++m) {
+        if (!menu_on && m != 4) continue;
+        for (int splits = 1; splits <= (EPI == EPI_RESID ? 4 : 1); splits *= 2) {
+            if (ks % splits != 0 || ks / splits < 4) continue;
+            const double c = ring_cost(RING_MENU[m], a.N, a.K, t_pad, splits, cu_count);
+            if (c < best_cost) { best_cost = c; best = m; best_splits = splits; }
+        }
+    }
+    if (best_cost >= 1e30) return fail(SQE_ERR_INVALID, "encoder gemm: no ring tile fits N / padded token count");
+    const RingShape sh = RING_MENU[best];
+    p.n_tiles = a.N / (2 * sh.fm * 16);
+    p.t_tiles = t_pad / (4 * sh.fn * 16);
+    p.splits = best_splits;
+    p.split_stride = split_stride;
+    if (splits_out) *splits_out = best_splits;
+    const int tiles = p.n_tiles * p.t_tiles;
+    switch (best) {
+        case 0: return launch_gemm_ring_shape<EPI, 2, 1, 4>(p, tiles, stream);
+        case 1: return launch_gemm_ring_shape<EPI, 4, 1, 4>(p, tiles, stream);
+        case 2: return launch_gemm_ring_shape<EPI, 6, 1, 4>(p, tiles, stream);
+        case 3: return launch_gemm_ring_shape<EPI, 8, 1, 3>(p, tiles, stream);
+        case 4: return launch_gemm_ring_shape<EPI, 4, 2, 4>(p, tiles, stream);
+        case 5: return launch_gemm_ring_shape<EPI, 6, 2, 3>(p, tiles, stream);
+        default: return launch_gemm_ring_shape<EPI, 8, 2, 3>(p, tiles, stream);
+    }
 }
 
 // A handful of tokens (T <= 64: one query, as the reference issues it): every GEMM of the layer is a few MB of

@@ -106,6 +106,7 @@ struct I8ScanArgs {
     const int8_t* db8; int64_t tile_stride; const uint32_t* sxi;
     const int8_t* q8; int q_pitch; const int* thr_int;
     int64_t n_rows; int K, B, b_pad, n_tiles, n_chunks, qblocks;
+    int bn;                              // queries per workgroup tile: 256 (ping-pong kernel), 128 or 64 (staged kernels, HBM-bound)
     uint64_t* cand; int* cand_cnt;      // the bf16 scan's candidate lists: [n_chunks, b_pad, CAND_CAP], [n_chunks, b_pad]
 };
 int launch_scan_i8(const I8ScanArgs& args, hipStream_t stream);

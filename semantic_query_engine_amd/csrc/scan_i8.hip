@@ -434,15 +434,195 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
     for (int i = tid; i < BNQ; i += SCAN_THREADS) p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (<= 128 queries): the staged form of scan.hip -- one barrier per 128-element K step, 3-stage LDS ring for
+// the DB operand (two K steps of DMA in flight per CU), one 1-KiB row-scale piece per tile -- HBM-bound like its bf16
+// twin, at half the bytes per row.  Same collect semantics as the ping-pong kernel above.
+template <int WM, int WN, int FM, int FN, int NST, int NSTB>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_i8_small_kernel(I8KernelArgs p) {
+    constexpr int BM = WM * FM * 16;
+    constexpr int BN = WN * FN * 16;
+    static_assert(BM == SCAN_BM && WM * WN == SCAN_NWAVES, "256-row DB tile, 8 waves");
+    constexpr int ROWB_ = 128;                               // bytes per row per K step (128 int8 elements)
+    constexpr int A_BYTES = BM * ROWB_, B_BYTES = BN * ROWB_;
+    constexpr int OFF_B = NST * A_BYTES;
+    constexpr int OFF_SC = OFF_B + NSTB * B_BYTES;           // 2 x [256] u32 row scales
+    constexpr int OFF_C = OFF_SC + 2048;                     // int [BN] list lengths
+    constexpr int PIECES_A = BM / 8 / SCAN_NWAVES, PIECES_B = BN / 8 / SCAN_NWAVES;
+    static_assert((BN / 8) % SCAN_NWAVES == 0, "every wave issues the same number of query pieces");
+    constexpr int IN_FLIGHT = PIECES_A * (NST - 2) + PIECES_B * (NSTB - 2);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int logical = blockIdx.x;
+    const int G = gridDim.x;
+    if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
+    const int q0 = qb * BN;
+    int tile_begin, tile_end;
+    chunk_tile_range(p.n_tiles, p.n_chunks, chunk, tile_begin, tile_end);
+    const int nt = tile_end - tile_begin;
+    const int KS = p.K / 128;
+    const size_t ldB = (size_t)p.q_pitch;
+    int* cnt = reinterpret_cast<int*>(smem + OFF_C);
+    for (int i = tid; i < BN; i += SCAN_THREADS) cnt[i] = 0;
+    uint64_t* cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    const int q_live = min(BN, p.B - q0);
+    const char* qbase = reinterpret_cast<const char*>(p.q8) + (size_t)q0 * ldB;
+    const char* dbbase = reinterpret_cast<const char*>(p.db8) + (long long)tile_begin * p.tile_stride;
+    const char* scales_src = reinterpret_cast<const char*>(p.sxi + (size_t)tile_begin * SCAN_BM);
+    const int total = nt * KS;
+
+    int thr[FN];
+#pragma unroll
+    for (int c = 0; c < FN; ++c) thr[c] = p.thr_int[q0 + wn * (FN * 16) + c * 16 + (lane & 15)];
+
+    // DMA of one stage: DB rows from the TILED copy (K step s = blocks 2 s and 2 s + 1 of the tile: chunk c < 4 of row r
+    // at block 2 s + r * 64 + c * 16, chunks 4-7 in the next block), query rows row-major.  Piece g = 8 rows of 128 B;
+    // lane l writes chunk position l & 7 of row 8 g + (l >> 3), which holds logical chunk (l & 7) ^ ((row >> 1) & 7).
+    int d_entry = 0, d_ks = 0, q_ks = 0;
+    auto issue_db = [&](int s_idx) {
+        char* buf = smem + (s_idx % NST) * A_BYTES;
+        const char* base = dbbase + (long long)d_entry * p.tile_stride + (long long)d_ks * (2 * BLOCK_BYTES);
+        if (wave == 0 && d_ks == 0) lds_dma16(scales_src + (long long)d_entry * 1024 + lane * 16, smem + OFF_SC + (d_entry & 1) * 1024);
+#pragma unroll
+        for (int it = 0; it < PIECES_A; ++it) {
+            const int g = it * SCAN_NWAVES + wave;
+            const int r = g * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            lds_dma16(base + (c >> 2) * BLOCK_BYTES + r * HALF_BYTES + (c & 3) * 16, buf + g * 1024);
+        }
+        if (++d_ks == KS) { d_ks = 0; ++d_entry; }
+    };
+    auto issue_q = [&](int s_idx) {
+        char* buf = smem + OFF_B + (s_idx % NSTB) * B_BYTES;
+#pragma unroll
+        for (int it = 0; it < PIECES_B; ++it) {
+            const int g = it * SCAN_NWAVES + wave;
+            const int r = g * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            lds_dma16(qbase + (size_t)r * ldB + (size_t)q_ks * ROWB_ + c * 16, buf + g * 1024);
+        }
+        if (++q_ks == KS) q_ks = 0;
+    };
+    for (int s = 0; s < NST - 1 && s < total; ++s) issue_db(s);
+    for (int s = 0; s < NSTB - 1 && s < total; ++s) issue_q(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    i32x4 acc[FM][FN];
+    int entry = 0, ks = 0;
+    for (int s = 0; s < total; ++s) {
+        const char* tA = smem + (s % NST) * A_BYTES;
+        const char* tB = smem + OFF_B + (s % NSTB) * B_BYTES;
+        const bool more = s + NST - 1 < total;
+        if (NSTB < NST && s + NSTB - 1 < total) issue_q(s + NSTB - 1);
+        if (more) issue_db(s + NST - 1);
+        if (NSTB == NST && more) issue_q(s + NSTB - 1);
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            i32x4 a[FM], b[FN];
+            const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * (FM * 16) + i * 16 + (lane & 15);
+                a[i] = *reinterpret_cast<const i32x4*>(tA + r * ROWB_ + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * (FN * 16) + j * 16 + (lane & 15);
+                b[j] = *reinterpret_cast<const i32x4*>(tB + r * ROWB_ + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks == KS - 1) {
+            // finished tile: scale by the rows' scales, test against the thresholds, append the survivors
+            const i32x4* sc = reinterpret_cast<const i32x4*>(smem + OFF_SC + (entry & 1) * 1024 + (wm * (FM * 16) + (lane >> 4) * 4) * 4);
+            int mx[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mx[j] = (int)0x80000000;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const i32x4 sv = sc[i * 4];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = __mul24(acc[i][j][r], sv[r]);
+                    mx[j] = max(max(mx[j], acc[i][j][0]), acc[i][j][1]);
+                    mx[j] = max(max(mx[j], acc[i][j][2]), acc[i][j][3]);
+                }
+            }
+            const int64_t tile_row0 = (int64_t)(tile_begin + entry) * SCAN_BM;
+            const bool partial = tile_row0 + SCAN_BM > p.n_rows;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if (!__any(mx[j] >= thr[j])) continue;
+                const int qcol = wn * (FN * 16) + j * 16 + (lane & 15);
+                const bool live = qcol < q_live;
+                uint64_t* list = cand_base + (size_t)qcol * CAND_CAP;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = tile_row0 + wm * (FM * 16) + i * 16 + (lane >> 4) * 4 + r;
+                        if (live && acc[i][j][r] >= thr[j] && (!partial || row < p.n_rows)) {
+                            const int slot = atomicAdd(&cnt[qcol], 1);
+                            if (slot < CAND_CAP) list[slot] = make_key_i32(acc[i][j][r], (uint32_t)row);
+                        }
+                    }
+            }
+        }
+        ++ks;
+        if (ks == KS) { ks = 0; ++entry; }
+        if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (IN_FLIGHT == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        static_assert(IN_FLIGHT == 4 || IN_FLIGHT == 5, "counted wait");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < BN; i += SCAN_THREADS) p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
+}
+
+template <int WM, int WN, int FM, int FN, int NST, int NSTB>
+int launch_small(const I8KernelArgs& k, hipStream_t stream) {
+    constexpr int BN = WN * FN * 16;
+    constexpr int LDS = (NST * SCAN_BM + NSTB * BN) * 128 + 2048 + BN * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = scan_i8_small_kernel<WM, WN, FM, FN, NST, NSTB>;
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
+    hipLaunchKernelGGL(kern, dim3(k.n_chunks * k.qblocks), dim3(SCAN_THREADS), LDS, stream, k);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
 }  // namespace
 
 int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
-    if (a.K % 64 != 0 || a.K < 256) return fail(SQE_ERR_INVALID, "int8 scan: dim must be a multiple of 64, >= 256");
-    if (a.b_pad % BNQ != 0 || a.qblocks * BNQ != a.b_pad) return fail(SQE_ERR_INVALID, "int8 scan: query block must be 256");
+    if (a.K % 128 != 0 || a.K < 256) return fail(SQE_ERR_INVALID, "int8 scan: dim must be a multiple of 128, >= 256");
+    if (a.bn != 64 && a.bn != 128 && a.bn != BNQ) return fail(SQE_ERR_INVALID, "int8 scan: query block must be 64, 128 or 256");
+    if (a.qblocks * a.bn != a.b_pad) return fail(SQE_ERR_INVALID, "int8 scan: padded batch must be a whole number of query blocks");
     I8KernelArgs k;
     k.db8 = a.db8; k.tile_stride = a.tile_stride; k.sxi = a.sxi; k.q8 = a.q8; k.q_pitch = a.q_pitch; k.thr_int = a.thr_int;
     k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = a.b_pad; k.n_tiles = a.n_tiles; k.n_chunks = a.n_chunks; k.qblocks = a.qblocks;
     k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.dbg = 0;
+    if (a.bn == 64) return launch_small<8, 1, 2, 4, 3, 3>(k, stream);          // the tilings of scan.hip's 64- / 128-query kernels
+    if (a.bn == 128) return launch_small<4, 2, 4, 4, 3, 2>(k, stream);
     auto kern = scan_i8_pp_kernel;
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(a.n_chunks * a.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);

@@ -8,7 +8,7 @@ make -C $C KNOBS=1 -j16 > /dev/null || exit 1
 make -C $C KNOBS=1 STAMPS=1 OBJDIR=/tmp/st1 OUT=/tmp/libsqe_st1.so -j16 > /dev/null || exit 1
 make -C $C KNOBS=1 STAMPS=2 OBJDIR=/tmp/st2 OUT=/tmp/libsqe_st2.so -j16 > /dev/null || exit 1
 make -C $C KNOBS=1 COUNTERS=1 OBJDIR=/tmp/cnt OUT=/tmp/libsqe_cnt.so -j16 > /dev/null || exit 1
-run() { env SQE_LIB=$1 SQE_DBG=$2 python bench.py --steps 3 --warmup 2 --rows 10000000 --batch $3 --no-cpu-baseline --no-gemm-ref --recall-queries 16 2>&1 >/dev/null | grep "sqe dbg" | tail -${4:-40}; }
+run() { env SQE_LIB=$1 SQE_DBG=$2 python bench.py --scan-mode ${SCAN_MODE:-bf16} --no-second-leg --steps 3 --warmup 2 --rows 10000000 --batch $3 --no-cpu-baseline --no-gemm-ref --recall-queries 16 2>&1 >/dev/null | grep "sqe dbg" | tail -${4:-40}; }
 for b in ${1:-1024 256}; do
   echo "== knobs build, SQE_DBG=32, batch $b"; run $C/../libsqe_knobs.so 32 $b 1
   echo "== STAMPS=1, batch $b"; run /tmp/libsqe_st1.so 32 $b

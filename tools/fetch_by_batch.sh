@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): tools/fetch_by_batch.sh -> L2 fills (FETCH_SIZE x 2 KiB) per scan launch at batch 256 / 512 / 1024: one, two, four workgroups per DB chunk
 export TMPDIR=/tmp
 for b in 256 512 1024; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fb_$b -- python3 bench.py --steps 3 --warmup 1 --rows 10000000 --no-cpu-baseline --no-gemm-ref --recall-queries 8 --batch $b > /dev/null 2> gpurun_out/pmc_fb_$b.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fb_$b -- python3 bench.py --scan-mode ${SCAN_MODE:-bf16} --no-second-leg --steps 3 --warmup 1 --rows 10000000 --no-cpu-baseline --no-gemm-ref --recall-queries 8 --batch $b > /dev/null 2> gpurun_out/pmc_fb_$b.err
   python3 - <<PY
 import csv, glob
 tot = n = 0

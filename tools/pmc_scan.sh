@@ -4,16 +4,17 @@
 # needs its own pass; SQ counters 8 per pass).
 tag=$1; shift
 export TMPDIR=/tmp
-args="--steps 3 --warmup 1 --rows ${PMC_ROWS:-10000000} --no-cpu-baseline --no-gemm-ref --recall-queries 8 --batch ${PMC_BATCH:-1024}"
+mode=${PMC_MODE:-bf16}     # bf16 | int8: which first pass is profiled (the kernel filter below follows)
+args="--steps 3 --warmup 1 --rows ${PMC_ROWS:-10000000} --no-cpu-baseline --no-gemm-ref --recall-queries 8 --batch ${PMC_BATCH:-1024} --scan-mode $mode --no-second-leg"
 mem_passes=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum")
 [ "${PMC_SQ_ONLY:-0}" = "1" ] && mem_passes=()
 for pass in "${mem_passes[@]}" \
-            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS" \
+            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_I8" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   env "$@" rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}/${name} -- python3 bench.py $args > gpurun_out/pmc_${tag}_${name}.json 2> gpurun_out/pmc_${tag}_${name}.err || echo "pass $name failed"
 done
-sha=$(python3 -c "import bench; print(bench.scan_source_hash())")
+sha=$(python3 -c "import bench; print(bench.scan_source_hash('$mode'))")
 python3 - <<PY
 import csv, glob, collections, json
 tot = {}
@@ -24,7 +25,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_${tag}/*/")):
             name = r["Kernel_Name"]
             # the main scan launches only (the collect-mode instantiation <..., true> exits at once
             # when every query is certified)
-            if "scan_bf16_p" in name or ("scan_bf16_kernel" in name and "false" in name):
+            if ("$mode" == "int8" and "scan_i8_" in name) or ("$mode" != "int8" and ("scan_bf16_p" in name or ("scan_bf16_kernel" in name and "false" in name))):
                 a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
         for k, (v, n) in acc.items():
             print("${tag}", k, "per_launch=%.6g" % (v / max(n, 1)), "launches=%d" % n)
@@ -34,7 +35,7 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     # (MI355X_MICROARCH.md, HBM section): double FETCH_SIZE, take WRITE_SIZE as is
     fetch = tot["FETCH_SIZE"] * 1024 * 2
     write = tot["WRITE_SIZE"] * 1024
-    json.dump({"rows": int("${PMC_ROWS:-10000000}"), "batch": int("${PMC_BATCH:-1024}"), "tag": "${tag}", "scan_src_sha": "${sha}",
+    json.dump({"rows": int("${PMC_ROWS:-10000000}"), "batch": int("${PMC_BATCH:-1024}"), "tag": "${tag}", "scan_mode": "$mode", "scan_src_sha": "${sha}",
                "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                "hbm_bytes_per_launch": fetch + write,
                "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, separate --pmc passes, "

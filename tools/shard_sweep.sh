@@ -13,5 +13,5 @@ for n in (1, 2, 4, 8):
     cases.append({"rows_per_shard": rows, "equivalent_gpus": n, "queries_per_s": d["value"], "ms_per_step": d["ms_per_step"],
                   "stage_ms": d["stage_ms"], "recall_at_10": d["recall_at_10"], "mfma_tflops": d["roofline"]["mfma_tflops"]})
 print(json.dumps({"what": "one MI355X running the per-rank work of an N-way row shard of the 10M x 1024 index, batch 1024 "
-                          "(python bench.py --rows R): the all-gather of [B,k] and the merge kernel are not included", "cases": cases}, indent=1))
+                          "(python bench.py --scan-mode ${SCAN_MODE:-bf16} --no-second-leg --rows R): the all-gather of [B,k] and the merge kernel are not included", "cases": cases}, indent=1))
 PY
