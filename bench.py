@@ -273,6 +273,7 @@ def main():
                          "certificate.  With int8 (the default) a second, bf16 leg of the same K steps is timed afterwards and "
                          "reported beside it (`bf16_scan`); --no-second-leg skips it")
     ap.add_argument("--no-second-leg", action="store_true")
+    ap.add_argument("--i8-sample", default="", help="int8 mode: 'step,m' of the threshold pass (default: the library's 50,32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--cpu-hnsw-rows", type=int, default=50_000,
@@ -353,6 +354,11 @@ def main():
 
     def step():
         return searcher.search(q, k)
+
+    if args.i8_sample:
+        st_, m_ = (int(v) for v in args.i8_sample.split(","))
+        idx.set_option("i8_sample_step", st_)
+        idx.set_option("i8_sample_m", m_)
 
     def timed_leg(mode: str):
         """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize, max over ranks."""

@@ -109,7 +109,8 @@ int index_update_impl(sqe_index* idx, const int64_t* rows_dev, const float* x_de
     if (idx->i8db.p && idx->i8_cap_tiles == idx->cap / SCAN_BM)
         SQE_TRY(launch_quantize_rows_i8(idx->master, rows_dev, 0, n, idx->dim, idx->i8db.as<int8_t>(), idx->i8_tile_stride,
                                         idx->i8sxi.as<uint32_t>(), idx->i8resid_max.as<uint32_t>(), s));
-    else idx->i8_rows = 0;      // the index grew since the copy was made: the next search rebuilds it from the master, whole
+    else idx->i8_rows = 0;
+    idx->i8_dx_stale = true;      // the index grew since the copy was made: the next search rebuilds it from the master, whole
     return SQE_OK;
 }
 
@@ -375,6 +376,9 @@ int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
     } else if (k == "i8_sample_step") {
         if (value < 1 || value > 4096) return fail(SQE_ERR_INVALID, "i8_sample_step must be in [1, 4096]");
         idx->i8_sample_step = (int)value;
+    } else if (k == "i8_max_resid") {
+        if (!(value > 0)) return fail(SQE_ERR_INVALID, "i8_max_resid must be > 0");
+        idx->i8_max_resid = value;
     } else if (k == "i8_sample_m") {
         if (value < 1 || value > 64) return fail(SQE_ERR_INVALID, "i8_sample_m must be in [1, 64]");
         idx->i8_sample_m = (int)value;
@@ -436,6 +440,16 @@ static int ensure_i8_copy(sqe_index* idx, hipStream_t s) {
         SQE_TRY(launch_quantize_rows_i8(idx->master, nullptr, idx->i8_rows, n_rows - idx->i8_rows, K, idx->i8db.as<int8_t>(), stride,
                                         idx->i8sxi.as<uint32_t>(), idx->i8resid_max.as<uint32_t>(), s));
         idx->i8_rows = n_rows;
+        idx->i8_dx_stale = true;
+    }
+    if (idx->i8_dx_stale) {
+        // one 4-byte read-back per batch of newly quantised (or overwritten) rows: the host decides from it whether the
+        // int8 bound is worth using at all (index_search_impl)
+        uint32_t bits = 0;
+        SQE_HIP(hipMemcpyAsync(&bits, idx->i8resid_max.p, 4, hipMemcpyDeviceToHost, s));
+        SQE_HIP(hipStreamSynchronize(s));
+        memcpy(&idx->i8_dx, &bits, 4);
+        idx->i8_dx_stale = false;
     }
     return SQE_OK;
 }
@@ -563,8 +577,12 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
     const int step8 = idx->i8_sample_step, m8 = idx->i8_sample_m;
     const bool use_i8 = idx->scan_mode == SQE_SCAN_INT8_RESCORE && certify && K >= 256 && K % 128 == 0 && k <= m8 &&
                         n_rows >= idx->i8_min_rows && n_rows >= (int64_t)step8 * SCAN_BM * 4;
+    bool i8_ok = use_i8;
     if (use_i8) {
         SQE_TRY(ensure_i8_copy(idx, s));
+        i8_ok = idx->i8_dx <= (float)idx->i8_max_resid;      // else: the bf16 scan below
+    }
+    if (i8_ok) {
         const int q8_pitch = K + 128;
         const int n_tiles_s = (plan.n_tiles + step8 - 1) / step8;
         ScanPlan ps = make_scan_plan((int64_t)n_tiles_s * SCAN_BM, B, auto_kp(idx, m8), c->cu_count, m8);

@@ -145,6 +145,7 @@ struct GemmArgs {
     int splits;           // split-K factor (ring kernel, EPI_RESID only): split s writes its partial sum to
     size_t split_stride;  //   out + s * split_stride floats; bias and residual are added by split 0
     int t_tiles;
+    int xcd_patches;      // gemm_ring_kernel: XCD-aware tile walk (0: linear)
     int pp_stagger;       // gemm_pp_kernel: half of a group's waves read their operands before they issue their DMA pieces
     int pp_dbg;           // gemm_pp_kernel, knobs build, timing only: 2 = no stores (results wrong), 4 = phase stamps (STAMPS build)
 };
@@ -824,8 +825,28 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int tiles = p.n_tiles * p.t_tiles;
-    const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int nt = tile % p.n_tiles, tt = tile / p.n_tiles;
+    // Workgroups b and b + 8 share an XCD and its 4 MiB L2 (speed only).  When the tile grid cuts into 4 x 2 patches, XCD x
+    // takes patch (x % 4, x / 4) -- a quarter of the weight tiles against half of the token tiles, all K slices of a tile
+    // together -- so that what its 32 workgroups stream is a few MB that stay in its L2; a linear walk gives every XCD two
+    // weight tiles against ALL tokens (at 64 x 32 tokens: 4.8 MB per XCD, served from the Infinity Cache at half the rate).
+    int split, nt, tt;
+    {
+        const int G = gridDim.x;
+        const int nq = p.n_tiles / 4, tq = p.t_tiles / 2;
+        if (p.xcd_patches && (p.n_tiles & 3) == 0 && (p.t_tiles & 1) == 0 && (G & 7) == 0) {
+            const int x = blockIdx.x & 7, j = blockIdx.x >> 3;          // j < nq * tq * splits
+            const int per = nq * tq;
+            split = j / per;
+            const int jj = j - split * per;
+            nt = (x & 3) * nq + jj % nq;
+            tt = (x >> 2) * tq + jj / nq;
+        } else {
+            split = blockIdx.x / tiles;
+            const int tile = blockIdx.x % tiles;
+            nt = tile % p.n_tiles;
+            tt = tile / p.n_tiles;
+        }
+    }
     const int n0 = nt * BNW, t0 = tt * BT;
     const size_t ld = (size_t)p.K * 2;
     const int KS = p.K / 64 / p.splits;
@@ -960,17 +981,47 @@ int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_st
     for (int m = 0; m < 7; ++m) {
         if (!menu_on && m != 4) continue;
         for (int splits = 1; splits <= (EPI == EPI_RESID ? 4 : 1); splits *= 2) {
-            if (ks % splits != 0 || ks / splits < 4) continue;
+            if (splits > 1 && (ks % splits != 0 || ks / splits < 4)) continue;
             const double c = ring_cost(RING_MENU[m], a.N, a.K, t_pad, splits, cu_count);
             if (c < best_cost) { best_cost = c; best = m; best_splits = splits; }
         }
     }
     if (best_cost >= 1e30) return fail(SQE_ERR_INVALID, "encoder gemm: no ring tile fits N / padded token count");
+    if (EPI == EPI_RESID) {
+        // The two N = hidden GEMMs write fp32 partial sums that the LayerNorm kernel adds up: every extra K slice is
+        // another T x N x 4 bytes written and read, which the cycle model above does not see.  Measured (tools/ring_tune.py,
+        // whole encoder, 64 x 32 and 64 x 16 tokens, profiles/r03_configs/ring_tune_*.jsonl): out-proj (K = hidden) is
+        // fastest on 64 x 64 tiles with NO split (3.03 -> 2.77 ms and 2.06 -> 1.92 ms against the model's 256 x 128 / 4
+        // slices), FFN-down (K = 4 x hidden) on 128 x 128 / 2 slices from 2,048 tokens on and 128 x 64 / 2 slices below.
+        // These rules cover 1,024-2,048 padded tokens (what was measured); elsewhere the model decides.
+        if (t_pad >= 1024 && t_pad <= 2048 && a.N % 128 == 0) {
+            if (a.K <= a.N) { best = 0; best_splits = 1; }
+            else if (t_pad >= 2048) { best = 4; best_splits = ks % 2 == 0 && ks / 2 >= 4 ? 2 : 1; }
+            else { best = 1; best_splits = ks % 2 == 0 && ks / 2 >= 4 ? 2 : 1; }
+        }   // other token counts: the model's choice (1 x 128 tokens: 1.84 -> 1.28 ms against the r02 rule; 64 x 128: 7.63 -> 7.34)
+    }
+    {
+        // knobs build, tuning runs (tools/ring_tune.sh): SQE_RING_FORCE_<EPI>_K<K>="menu index:splits" pins the choice for
+        // the GEMMs of that epilogue and depth; SQE_RING_XCD=0 switches the XCD-aware tile walk off
+        char name[64];
+        snprintf(name, sizeof name, "SQE_RING_FORCE_%d_K%d", (int)EPI, a.K);
+        const char* e = knob_env(name);
+        int m = -1, sp = 1;
+        if (e && sscanf(e, "%d:%d", &m, &sp) >= 1 && m >= 0 && m < 7 && ring_cost(RING_MENU[m], a.N, a.K, t_pad, 1, cu_count) < 1e30 &&
+            (sp == 1 || (EPI == EPI_RESID && (sp == 2 || sp == 4) && ks % sp == 0))) {
+            best = m;
+            best_splits = sp;
+        }
+    }
     const RingShape sh = RING_MENU[best];
     p.n_tiles = a.N / (2 * sh.fm * 16);
     p.t_tiles = t_pad / (4 * sh.fn * 16);
     p.splits = best_splits;
     p.split_stride = split_stride;
+    {
+        static const bool xcd_off = [] { const char* e = knob_env("SQE_RING_XCD"); return e && e[0] == '0'; }();
+        p.xcd_patches = xcd_off ? 0 : 1;
+    }
     if (splits_out) *splits_out = best_splits;
     const int tiles = p.n_tiles * p.t_tiles;
     switch (best) {

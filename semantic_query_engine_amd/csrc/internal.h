@@ -201,8 +201,15 @@ struct sqe_index {
     int64_t i8_rows = 0;           // rows [0, i8_rows) of the int8 copy are current (filled lazily by the first search after an add)
     sqe::DevBuf q8, q8sqi, q8resid, i8thr_int, i8thr_eff, i8cos_s, i8ids_s, i8stats;   // per search
     int64_t i8_min_rows = 1000000; // below this many rows (or batches <= 128, dim < 256, k > 32) the bf16 scan answers
-    int i8_sample_step = 50;       // the threshold pass scans every i8_sample_step-th tile with the bf16 kernels ...
-    int i8_sample_m = 32;          // ... and the collect threshold of a query is its m-th best true cosine there
+    int i8_sample_step = 100;      // the threshold pass scans every i8_sample_step-th tile with the bf16 kernels ...
+    int i8_sample_m = 20;          // ... and the collect threshold of a query is its m-th best true cosine there (~step x m = 2,000
+                                   //   rows collected per query; r03 sweep, profiles/r03_search/i8_sample_sweep.log: a proof starts
+                                   //   to fail when fewer than ~380 rows of a query are collected, i.e. when >= m sample rows beat
+                                   //   the rank-380 score -- Poisson(3.8) >= 20: 1e-8 per query; any failure costs a 3 ms bf16 pass)
+    float i8_dx = 0.f;             // host copy of the int8 residual maximum (refreshed when rows were quantised)
+    bool i8_dx_stale = true;
+    double i8_max_resid = 0.02;    // rows that quantise worse than this (one huge element: a one-hot row has 0.07 at dim 1024) would
+                                   //   make every certificate fail: the index then answers with the bf16 scan
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
     bool internal = false;         // sub-index of another object (IVF coarse quantiser): runs under its owner's lock and stream
     sqe::GroupIndex* group = nullptr;   // index of a multi-device context: one shard per member device (group.hip)

@@ -2,7 +2,7 @@
 // matter, select the exact top-k and prove that no uncollected row can belong to it.  One workgroup per query.
 //
 //   keys   (int8 score, row) of every row whose scaled int8 score reached the query's threshold, from the (chunk, query)
-//          lists; sorted best first in LDS (bitonic, <= 4096 keys);
+//          lists; sorted best first in LDS (bitonic, <= 8192 keys);
 //   stage 1  the 64 best by int8 score are re-scored against the fp32 master: t1 = k-th best TRUE cosine among them, a
 //          lower bound of the final k-th cosine;
 //   stage 2  a row whose estimated score is below t1 - eps has a true cosine below t1: it cannot enter the top-k.  Every
@@ -21,7 +21,7 @@ namespace sqe {
 
 namespace {
 
-constexpr int KEY_CAP = 4096;      // collected keys per query held in LDS
+constexpr int KEY_CAP = 8192;      // collected keys per query held in LDS (~2,000 expected: the sample's threshold is a noisy estimate)
 constexpr int RS_CAP = 2048;       // rows re-scored per query
 constexpr int STAGE1 = 64;
 

@@ -136,10 +136,35 @@ def test_rows_with_outlier_elements_zero_rows_and_partial_tile(ctx):
     q[:64] = x[spikes[:64]] + 0.5 * q[:64]                    # queries whose neighbours are spike rows
     q[64:70] = x[200:206] * 1e-10                             # neighbours among the huge rows (the tiny ones normalise to ~0: 1e-9 rule)
     idx = _i8_index(ctx, d, step=4)
+    idx.set_option("i8_max_resid", 1.0)                      # keep the int8 pass on although the spike rows quantise badly
     idx.add(x)
     cos, ids, st = _check(ctx, idx, x, q, k)
     assert np.array_equal(ids[:64, 0], spikes[:64])
     assert np.array_equal(ids[64:70, 0], np.arange(200, 206))
+    idx.close()
+
+
+def test_a_row_that_quantises_badly_switches_the_index_to_bf16(ctx):
+    """The int8 bound uses the LARGEST rounding residual of the index: one one-hot row (residual 0.07 at dim 1024 against
+    0.014 for Gaussian rows) would make every certificate fail and every query pay the int8 pass AND the bf16 pass.  The
+    index notices (option i8_max_resid, default 0.02) and answers with the bf16 scan; overwriting the row brings int8 back."""
+    rng = np.random.default_rng(61)
+    d, n, b, k = 1024, 60_000, 300, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    idx = _i8_index(ctx, d, step=4, m=64)
+    idx.add(x)
+    _, _, st = _check(ctx, idx, x, q, k)
+    assert st["i8_collected"] > 0
+    onehot = np.zeros((1, d), np.float32)
+    onehot[0, 5] = 1.0
+    x2 = np.concatenate([x, onehot])
+    idx.add(onehot)
+    _, _, st = _check(ctx, idx, x2, q, k, want_i8=False)
+    assert st["i8_collected"] == 0                                        # the bf16 scan answered
+    idx.set_option("i8_max_resid", 1.0)                                   # forced: int8 pass, every proof fails, bf16 pass -- still exact
+    _, _, st = _check(ctx, idx, x2, q, k)
+    assert st["uncertified"] == b
     idx.close()
 
 
