@@ -124,13 +124,12 @@ def cpu_baseline_hnsw(rows: int, b: int, k: int) -> dict:
     x = rng.standard_normal((rows, D), dtype=np.float32)
     q = rng.standard_normal((b, D), dtype=np.float32)
     q[: b // 2] = x[rng.integers(0, rows, b // 2)] + 0.1 * q[: b // 2]       # planted neighbours, as in the GPU run
-    # every host core this process may run on (the GPU box hands a one-GPU job a share of its host CPUs); the build
-    # takes per-node locks, beyond 32 threads they only contend
+    # the GPU box hands a one-GPU job a CPU share of 16 whatever the affinity mask says: more threads than that only thrash
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))
+    cores = max(1, min(cores, 16))
     t0 = time.perf_counter()
     h = HnswIndex(x, m=64, ef_construction=500, seed=0, threads=cores)
     build_s = time.perf_counter() - t0

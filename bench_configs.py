@@ -107,7 +107,10 @@ def cpu_encoder_baseline(cases, max_seconds: float = 40.0) -> dict:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, cores))
+    # a one-GPU job on the GPU box has a CPU share of 16 whatever the affinity mask says (256): r03's first run took
+    # 33 s for ONE 32-token text with 256 threads on that share
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
     cfg = transformers.BertConfig(vocab_size=BERT_LARGE["vocab_size"], hidden_size=1024, num_hidden_layers=24,
                                   num_attention_heads=16, intermediate_size=4096, max_position_embeddings=512,
                                   type_vocab_size=2, hidden_act="gelu", layer_norm_eps=1e-12)
@@ -239,6 +242,14 @@ def mode_ivf(args, ctx, dev):
     ci = torch.empty((b, k), device=dev); ji = torch.empty((b, k), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     ivf_ms = timed(lambda: ivf.search_device(q.data_ptr(), b, k, ci.data_ptr(), ji.data_ptr(), nprobe=nprobe), ctx.synchronize, 5)
+    # batch sweep, timed HERE: before the NumPy / OpenBLAS checks below, whose worker threads keep spinning on the box's 16-CPU
+    # share afterwards and delayed the host side of these short searches (r03: batch 1024 measured 7.2 ms after them against 4.4)
+    sweep_ms = {}
+    for bb in (1, 8, 64, 256, 1024):
+        if bb > b:
+            break
+        co = torch.empty((bb, k), device=dev); jo = torch.empty((bb, k), dtype=torch.int64, device=dev)
+        sweep_ms[bb] = timed(lambda: ivf.search_device(q.data_ptr(), bb, k, co.data_ptr(), jo.data_ptr(), nprobe=nprobe), ctx.synchronize, 10)
     # ---- the checks (64-query probe)
     probe = torch.cat([torch.arange(0, 32), torch.arange(b - 32, b)]).to(dev) if b >= 64 else torch.arange(b, device=dev)
     got = ji[probe].cpu().numpy()
@@ -265,8 +276,7 @@ def mode_ivf(args, ctx, dev):
     parity = float(np.mean(got == ref_ids))
     del xn_host
     # ---- batch sweep (r02 verdict: the reference issues B = 1, main.py:355): IVF at 1 / 8 / 64 / 256 / 1024 of the same
-    # queries, BEFORE the flat index is built (r03: with both 10 M-row indexes resident the same IVF searches measured
-    # 2-5 x slower).  Algorithmic bytes of a point: the rows of the DISTINCT lists its queries probe (from the exported
+    # queries (timed above).  Algorithmic bytes of a point: the rows of the DISTINCT lists its queries probe (from the exported
     # assignment and the oracle's probe order on the exported centroids) x D x 2.
     sweep = []
     cen64 = centroids.astype(np.float64)
@@ -275,7 +285,7 @@ def mode_ivf(args, ctx, dev):
     for bb in (1, 8, 64, 256, 1024):
         if bb > b:
             break
-        t_ivf = timed(lambda: ivf.search_device(q.data_ptr(), bb, k, ci.data_ptr(), ji.data_ptr(), nprobe=nprobe), ctx.synchronize, 10)
+        t_ivf = sweep_ms[bb]
         probes = np.argsort(-(qn_all[:bb] @ cen64.T), axis=1, kind="stable")[:, :nprobe]
         rows_touched = int(list_len[np.unique(probes)].sum())
         by = rows_touched * D * 2

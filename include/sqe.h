@@ -57,11 +57,13 @@ enum { SQE_INDEX_FLAT = 0, SQE_INDEX_IVF_FLAT = 1 };
  * master copy, and a per-query certificate (option "certify") proves that no row outside the re-scored set can
  * reach the k-th cosine -- the rounding of every scanned copy is measured and bounded -- with a bf16 collect pass
  * for the queries where the proof fails.
- *   BF16_RESCORE: bf16 MFMA scan with a fused top-k filter (default; every batch size, every index size);
- *   INT8_RESCORE: int8 MFMA first pass at twice the bf16 rate over a per-row-scaled int8 copy (+1 byte per element):
+ *   BF16_RESCORE: bf16 MFMA scan with a fused top-k filter (every batch size, every index size; what IVF indexes and
+ *                 every case outside the int8 conditions below run);
+ *   INT8_RESCORE (default of FLAT indexes): int8 MFMA first pass at twice the bf16 rate over a per-row-scaled int8 copy (+1 byte per element):
  *                 a 2 % row sample fixes per-query thresholds, the int8 scan collects every row above them, the
- *                 collected rows are re-scored in fp32.  Used for batches > 128 on FLAT indexes of >= "i8_min_rows"
- *                 rows (default 1 M), dim >= 256, k <= 32; everything else runs the bf16 scan.  Suited to rows whose
+ *                 collected rows are re-scored in fp32.  Used on FLAT indexes of >= "i8_min_rows" rows (default 1 M),
+ *                 dim >= 256 and a multiple of 128, k <= "i8_sample_m" (20), rows that quantise within "i8_max_resid";
+ *                 everything else runs the bf16 scan.  Suited to rows whose
  *                 elements are of similar magnitude (unit Gaussian-like embeddings): the int8 error bound is ~8 x the
  *                 bf16 one, and data on which it is too wide simply takes the bf16 pass.
  * (r02's header also listed an fp32 scan mode that was never built; it is gone.) */

@@ -107,7 +107,7 @@ int index_update_impl(sqe_index* idx, const int64_t* rows_dev, const float* x_de
     if (idx->ivf) SQE_TRY(ivf_rows_updated(idx, idx->ivf, rows_dev, n, s));   // only the overwritten rows are re-assigned
     // the int8 copy follows (rows past i8_rows are quantised again by the next search; the residual maximum only grows)
     if (idx->i8db.p && idx->i8_cap_tiles == idx->cap / SCAN_BM)
-        SQE_TRY(launch_quantize_rows_i8(idx->master, rows_dev, 0, n, idx->dim, idx->i8db.as<int8_t>(), idx->i8_tile_stride,
+        SQE_TRY(launch_quantize_rows_i8(idx->master, rows_dev, 0, n, idx->n.load(), idx->dim, idx->i8db.as<int8_t>(), idx->i8_tile_stride,
                                         idx->i8sxi.as<uint32_t>(), idx->i8resid_max.as<uint32_t>(), s));
     else idx->i8_rows = 0;
     idx->i8_dx_stale = true;      // the index grew since the copy was made: the next search rebuilds it from the master, whole
@@ -129,6 +129,10 @@ int index_create_impl(sqe_ctx* ctx, int dim, int kind, int nlist, bool internal,
     idx->kind = kind;
     idx->nlist = nlist;
     idx->internal = internal;
+    // FLAT indexes take the int8 first pass wherever it applies (>= i8_min_rows rows, dim >= 256 and a multiple of 128,
+    // k <= i8_sample_m, rows that quantise within i8_max_resid); everything else -- small indexes, IVF, the coarse quantiser's
+    // own index -- runs the bf16 scan.  Both are exact (sqe.h: SQE_SCAN_*).
+    idx->scan_mode = (kind == SQE_INDEX_FLAT && !internal) ? SQE_SCAN_INT8_RESCORE : SQE_SCAN_BF16_RESCORE;
     if (!internal) SQE_TRY(idx->ord.init());
     {
         // rows of the scanned copy are padded by one 128-B line by default: with a 2^n pitch every
@@ -437,7 +441,7 @@ static int ensure_i8_copy(sqe_index* idx, hipStream_t s) {
     }
     if (idx->i8_rows < n_rows) {
         StageTimer t(idx->ctx->prof, s, ST_ADD);
-        SQE_TRY(launch_quantize_rows_i8(idx->master, nullptr, idx->i8_rows, n_rows - idx->i8_rows, K, idx->i8db.as<int8_t>(), stride,
+        SQE_TRY(launch_quantize_rows_i8(idx->master, nullptr, idx->i8_rows, n_rows - idx->i8_rows, n_rows, K, idx->i8db.as<int8_t>(), stride,
                                         idx->i8sxi.as<uint32_t>(), idx->i8resid_max.as<uint32_t>(), s));
         idx->i8_rows = n_rows;
         idx->i8_dx_stale = true;
@@ -658,6 +662,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         c->last_scan_bytes.store(n_rows * (int64_t)K + (int64_t)B * K * 4 + (int64_t)B * k * 12);   // SURVEY 8(d) with s = 1 byte per element
         return SQE_OK;
     }
+    c->i8_valid.store(false);        // this search runs the bf16 first pass
     if (n_rows > 0) {
         StageTimer t(c->prof, s, ST_SCAN);
         ScanArgs a;
@@ -1195,6 +1200,7 @@ static void stats_reset_one(sqe_ctx* ctx) {
     std::lock_guard<std::mutex> lk(ctx->prof.mu);
     for (int i = 0; i < ST_COUNT; ++i) { ctx->prof.ms[i] = 0; ctx->prof.calls[i] = 0; }
     ctx->search_calls.store(0);
+    ctx->i8_valid.store(false);      // the int8 counters describe the last int8 search SINCE the reset
 }
 
 int sqe_stats_reset(sqe_ctx* ctx) {

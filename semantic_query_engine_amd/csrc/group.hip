@@ -25,8 +25,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <new>
+#include <thread>
 
 #include "internal.h"
 
@@ -65,8 +68,56 @@ size_t packed_part_bytes(int B, int k) { return ((size_t)B * k * 12 + 15) / 16 *
 
 }  // namespace
 
+// One enqueue thread per member beyond the leader (r03, r02 verdict item 8): a search enqueues ~15 launches, copies and
+// events per shard; from ONE host thread that was 0.46 ms for 8 shards of 1.25 M rows -- a fifth of one shard's 2.3 ms step
+// (profiles/r03_configs/group_host_cost.jsonl), and on P real GPUs the last shard would start that much late.  The
+// calling thread keeps shard 0; worker p sets its device once and runs shard p's closure; errors come back with their text
+// (sqe_last_error is thread-local).
+struct ShardWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, done = false, stop = false;
+    int rc = SQE_OK;
+    std::string err;
+    int dev = 0;
+    void loop() {
+        (void)hipSetDevice(dev);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || stop; });
+            if (stop) return;
+            std::function<int()> fn = std::move(task);
+            has_task = false;
+            lk.unlock();
+            const int r = fn();
+            std::string e = r == SQE_OK ? std::string() : std::string(sqe_last_error());
+            lk.lock();
+            rc = r;
+            err = std::move(e);
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> fn) {
+        std::lock_guard<std::mutex> lk(mu);
+        task = std::move(fn);
+        has_task = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        if (rc != SQE_OK) set_error(err);
+        return rc;
+    }
+};
+
 struct Group {
     int P = 0;
+    std::vector<std::unique_ptr<ShardWorker>> workers;   // [P - 1]: worker p - 1 enqueues for member p
     std::vector<int> devs;
     std::vector<sqe_ctx*> members;        // members[0] is the leader itself
     std::vector<char> peer_ok;            // leader memory is directly addressable from member p
@@ -180,12 +231,27 @@ int group_create(sqe_ctx* leader, const int* device_ids, int n, int exchange) {
     } else if (exchange == SQE_EXCHANGE_RCCL) {
         return fail(SQE_ERR_INVALID, "sqe_create_sharded: the RCCL exchange needs distinct devices (logical shards of one device use the copy exchange)");
     }
+    for (int p = 1; p < n; ++p) {
+        gp->workers.emplace_back(new ShardWorker);
+        ShardWorker* w = gp->workers.back().get();
+        w->dev = device_ids[p];
+        w->th = std::thread([w] { w->loop(); });
+    }
     return SQE_OK;
 }
 
 void group_destroy(sqe_ctx* leader) {
     Group* g = leader->group;
     if (!g) return;
+    for (auto& w : g->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->stop = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    g->workers.clear();
     for (size_t p = 0; p < g->comms.size(); ++p)
         if (g->comms[p]) (void)g->rccl.CommDestroy(g->comms[p]);
     for (size_t p = 1; p < g->members.size(); ++p) sqe_destroy(g->members[p]);
@@ -511,8 +577,8 @@ int group_index_search(sqe_index* idx, const float* q, int B, int k, int nprobe,
         SQE_HIP(hipSetDevice(g->devs[0]));
         SQE_HIP(hipEventRecord(gi->ev_q, sc.s(0)));
     }
-    // ---- every shard: queries in, local top-k into its slot of the gather buffer
-    for (int p = 0; p < P; ++p) {
+    // ---- every shard: queries in, local top-k into its slot of the gather buffer (shard 0 from this thread, shard p from worker p)
+    auto shard_step = [&, q, B, k, nprobe, on_device, qbytes, part, ib, rccl](int p) -> int {
         SQE_HIP(hipSetDevice(g->devs[p]));
         hipStream_t s = sc.s(p);
         // RCCL: every device holds the whole gather buffer (in-place all-gather); copy exchange: only the leader does
@@ -530,6 +596,23 @@ int group_index_search(sqe_index* idx, const float* q, int B, int k, int nprobe,
             qp = gi->qbuf[p]->as<float>();
         }
         SQE_TRY(index_search_impl(gi->shards[p], qp, B, k, nprobe, reinterpret_cast<float*>(slot + ib), reinterpret_cast<int64_t*>(slot), s));
+        return SQE_OK;
+    };
+    {
+        static const bool serial = [] { const char* e = knob_env("SQE_GROUP_SERIAL"); return e && e[0] == '1'; }();   // knobs build: the r02 form, for A/B
+        int rc = SQE_OK;
+        if (serial || g->workers.size() != (size_t)(P - 1)) {
+            for (int p = 0; p < P && rc == SQE_OK; ++p) rc = shard_step(p);
+        } else {
+            for (int p = 1; p < P; ++p) g->workers[p - 1]->post([&shard_step, p] { return shard_step(p); });
+            rc = shard_step(0);
+            for (int p = 1; p < P; ++p) {
+                const int r = g->workers[p - 1]->wait();
+                if (rc == SQE_OK) rc = r;
+            }
+        }
+        SQE_HIP(hipSetDevice(g->devs[0]));
+        if (rc != SQE_OK) return rc;
     }
     // ---- ONE exchange step
     if (rccl) {

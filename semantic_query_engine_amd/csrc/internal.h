@@ -208,7 +208,7 @@ struct sqe_index {
                                    //   the rank-380 score -- Poisson(3.8) >= 20: 1e-8 per query; any failure costs a 3 ms bf16 pass)
     float i8_dx = 0.f;             // host copy of the int8 residual maximum (refreshed when rows were quantised)
     bool i8_dx_stale = true;
-    double i8_max_resid = 0.02;    // rows that quantise worse than this (one huge element: a one-hot row has 0.07 at dim 1024) would
+    double i8_max_resid = 0.02;    // rows that quantise worse than this (one element 40 x the others: 0.05 at dim 1024) would
                                    //   make every certificate fail: the index then answers with the bf16 scan
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
     bool internal = false;         // sub-index of another object (IVF coarse quantiser): runs under its owner's lock and stream

@@ -92,10 +92,11 @@ int launch_scan_collect(const ScanPlan& plan, const ScanArgs& args, hipStream_t 
 // ------------------------------------------------------------------ int8 first-pass scan (quant.hip, scan_i8.hip, select_i8.hip)
 // Scale unit of the int8 copies of `dim`-d unit vectors: row scale = sxi * unit (quant.hip).
 float i8_scale_unit(int dim);
-// int8 copy of master rows [first_row, first_row + n) (rows != null: of the listed rows) into the TILED layout
-// (tile t at t * tile_stride; K slice h of row r at h * 16 KiB + (r % 256) * 64), row scales sxi[row], atomic max of the
-// rounding residual || x_hat - sxi unit x8 || (float bits).
-int launch_quantize_rows_i8(const float* master, const int64_t* rows, int64_t first_row, int64_t n, int dim, int8_t* out,
+// int8 copy of the 256-row TILES that hold master rows [first_row, first_row + n) (rows != null: the tiles of the n listed rows)
+// into the TILED layout (tile t at t * tile_stride; K slice h of row r at h * 16 KiB + (r % 256) * 64), ONE scale per tile
+// (written to sxi[row] of each of its rows), atomic max of the rounding residual || x_hat - sxi unit x8 || (float bits).
+// Rows >= n_rows of a tile are written as zero vectors.
+int launch_quantize_rows_i8(const float* master, const int64_t* rows, int64_t first_row, int64_t n, int64_t n_rows, int dim, int8_t* out,
                             int64_t tile_stride, uint32_t* sxi, uint32_t* resid_max, hipStream_t stream);
 // int8 copy of normalised query rows, row-major at q_pitch bytes; sqi[q], resid_rows[q]
 int launch_quantize_queries_i8(const float* qn, int B, int dim, int8_t* out, int q_pitch, uint32_t* sqi, float* resid_rows, hipStream_t stream);

@@ -16,9 +16,11 @@
 // Schedule: the ping-pong schedule of scan_pp.hip byte for byte -- a half-step is 64 int8 elements = 64 B per row, the same
 // LDS image, swizzle, DMA pieces and ds_read_b128 addresses as 32 bf16 elements -- with these differences:
 //   * DB tiles are read from the TILED int8 copy: a half-step is one contiguous 16 KiB block (quant.hip);
-//   * the last half-step of a tile issues its MFMAs fragment row by fragment row and multiplies the finished accumulators
-//     of the previous fragment row by their rows' scales (v_mul_i32_i24, under the MFMAs of the next row), folding the
-//     products into four running maxima; a wave whose maxima reach a threshold marks the tile;
+//   * every row of a tile carries the same scale (quant.hip), so the scale is applied to the lane's four thresholds, once per
+//     tile, not to the accumulators: the last half-step folds the RAW accumulators into four running maxima under its MFMAs
+//     exactly as the bf16 kernel does; a wave whose maxima reach a (conservative) threshold marks the tile, and the append
+//     path applies the exact predicate acc * s >= thr (the first r03 version scaled row by row: 128 v_mul_i32_i24 per wave
+//     and tile in a VALU-bound last phase);
 //   * marked tiles run the append path in one common phase (no cross-wave step follows it: no compaction exists);
 //   * the 256 row scales of a tile (1 KiB) arrive through one extra LDS-DMA piece per tile.
 #include <stdlib.h>
@@ -150,35 +152,50 @@ __device__ __forceinline__ void cmp_phase_mid(S8& P, i32x4 (&acc)[8][4], const A
     }
 }
 
-// Last half-step of a tile: MFMAs fragment row by fragment row; the 16 accumulators of fragment row fm - 1 are final by
-// then and are multiplied IN PLACE by the scales of their four rows (|acc| < 2^23 and scale < 2^16 by construction, the
-// product -- a cosine in units of S0^2 sqi -- below 2^31: quant.hip) and folded into the running maximum of their column
-// group.  Returns the wave-uniform mask of the column groups whose maximum reaches its query's threshold.
-__device__ __forceinline__ unsigned cmp_phase_last(i32x4 (&acc)[8][4], const AOps& a, const BOps& b, const i32x4* scales, const int (&thr)[4]) {
+// running max over the four scores of one accumulator fragment: 2 v_max3_i32
+__device__ __forceinline__ int fold_i32(int m, const i32x4& v) { return max(max(max(max(m, v[0]), v[1]), v[2]), v[3]); }
+
+// Last half-step of a tile, as scan_pp.hip's: MFMAs column group by column group; the MFMA of fragment (fm, fn) is followed
+// by the two v_max3_i32 that fold fragment (fm, fn - 1) -- final for 8 MFMAs by then -- into that group's running maximum
+// (order requested with sched_group_barrier), so the test rides under the MFMAs.  The accumulators stay RAW: every row of
+// the tile has the same scale s (quant.hip), so "acc * s >= thr" is tested as "acc >= tlo" with tlo <= ceil(thr / s), computed
+// once per tile and lane (tile_thresholds); the append path applies the exact predicate.  Returns the wave-uniform mask of
+// the column groups whose maximum reaches its (conservative) threshold.
+__device__ __forceinline__ unsigned cmp_phase_last(i32x4 (&acc)[8][4], const AOps& a, const BOps& b, const int (&tlo)[4]) {
     int mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-    i32x4 sc[8];
 #pragma unroll
-    for (int fm = 0; fm < 8; ++fm) sc[fm] = scales[fm * 4];          // rows fm * 16 + (lane >> 4) * 4 + 0..3: 16 B, fragments 64 B apart
-    auto finish = [&](int fm) {
+    for (int fn = 0; fn < 4; ++fn) {
+        if (fn > 1) asm("" : "+v"(mx[fn - 1]) : "v"(mx[fn - 2]));       // group fn - 1's chain of folds starts after group fn - 2's (scan_pp.hip)
 #pragma unroll
-        for (int fn = 0; fn < 4; ++fn) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[fm][fn][r] = __mul24(acc[fm][fn][r], sc[fm][r]);
-            mx[fn] = max(max(mx[fn], acc[fm][fn][0]), acc[fm][fn][1]);
-            mx[fn] = max(max(mx[fn], acc[fm][fn][2]), acc[fm][fn][3]);
+        for (int fm = 0; fm < 8; ++fm) {
+            acc[fm][fn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+            if (fn > 0) mx[fn - 1] = fold_i32(mx[fn - 1], acc[fm][fn - 1]);
         }
-    };
-#pragma unroll
-    for (int fm = 0; fm < 8; ++fm) {
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
-        if (fm > 0) finish(fm - 1);
     }
-    finish(7);
+    asm("" : "+v"(mx[3]) : "v"(mx[2]));
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) mx[3] = fold_i32(mx[3], acc[fm][3]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+    for (int t = 0; t < 24; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
     unsigned mask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) mask |= __any(mx[j] >= thr[j]) ? (1u << j) : 0u;
+    for (int j = 0; j < 4; ++j) mask |= __any(mx[j] >= tlo[j]) ? (1u << j) : 0u;
     return __builtin_amdgcn_readfirstlane(mask);
+}
+
+// conservative per-tile thresholds on the raw accumulators: tlo <= ceil(thr / s) for the tile's scale s >= 1 (float division, error
+// of a few ulp covered by the margin; |acc| < 2^23, so a threshold beyond +-1.5e7 behaves as "never" / "always")
+__device__ __forceinline__ void tile_thresholds(const int (&thr)[4], int s, int (&tlo)[4]) {
+    const float inv = 1.0f / (float)s;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float f = (float)thr[c] * inv;
+        tlo[c] = (int)floorf(f - fabsf(f) * 9.5367431640625e-07f) - 1;
+    }
 }
 
 __device__ __forceinline__ void read_operands(const S8& P, AOps& a, BOps& b, int j) {
@@ -236,11 +253,14 @@ __device__ __forceinline__ int pick_acc_i32(const i32x4 (&acc)[8][4], int t) {
 // append path of one column group of a finished tile (scan_common.h: filter_group, integer scores, no compaction)
 template <int J>
 __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t row_base, int64_t n_rows, bool partial, int qcol, bool live,
-                                              int thr, int* cnt, uint64_t* cand_base) {
+                                              int thr, int scale, int* cnt, uint64_t* cand_base) {
     unsigned m = 0;
+    // the exact predicate acc * s >= thr (|acc| < 2^23, s < 2^16, product < 2^31: quant.hip)
 #pragma unroll
-    for (int t = 31; t >= 0; --t)
-        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(acc[t >> 2][J][t & 3]), "v"(thr) : "vcc");
+    for (int t = 31; t >= 0; --t) {
+        const int v = __mul24(acc[t >> 2][J][t & 3], scale);
+        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(v), "v"(thr) : "vcc");
+    }
     if (partial) {                                  // last tile of the index: rows past the end are not rows
         const int left = (int)min((int64_t)SCAN_BM, max((int64_t)0, n_rows - row_base));
         unsigned valid = 0;
@@ -261,7 +281,7 @@ __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t 
     while (todo) {
         const int t = __builtin_ctz(todo);          // uniform
         todo &= todo - 1;
-        const int sc = pick_acc_i32<J>(acc, t);
+        const int sc = __mul24(pick_acc_i32<J>(acc, t), scale);
         if (m & (1u << t)) {
             const int64_t row = row_base + (t >> 2) * 16 + (t & 3);
             if (slot < CAND_CAP) list[slot] = make_key_i32(sc, (uint32_t)row);
@@ -356,9 +376,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         int j = 0;
         unsigned cols = 0;
         int* any_cols = flags + 8;
+        int tile_scale = 1;                // the finished tile's scale (every row of a tile has the same: quant.hip)
         auto last_phase = [&](int e) {
-            const i32x4* sc = reinterpret_cast<const i32x4*>(smem + OFF_SCALES + (e & 1) * 1024 + (P.wm * 128 + (lane >> 4) * 4) * 4);
-            cols = cmp_phase_last(acc, a, b, sc, thr);
+            tile_scale = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + OFF_SCALES + (e & 1) * 1024));
+            int tlo[4];
+            tile_thresholds(thr, tile_scale, tlo);
+            cols = cmp_phase_last(acc, a, b, tlo);
             if (cols != 0 && fresh_lane() == 0) *any_cols = 1;
         };
         // after the barrier that ends G1's last compute phase of entry e: every wave takes the same path
@@ -371,10 +394,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 const int64_t row_base = tile_row0 + P.wm * 128 + (fl >> 4) * 4;
                 const bool partial = tile_row0 + SCAN_BM > p.n_rows;
                 const int qc0 = P.wn * 64 + (fl & 15);
-                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], cnt, cand_base);
-                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], cnt, cand_base);
-                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], cnt, cand_base);
-                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], cnt, cand_base);
+                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base);
+                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base);
+                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base);
+                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base);
             }
             __builtin_amdgcn_sched_barrier(0);
             I8_BARRIER();

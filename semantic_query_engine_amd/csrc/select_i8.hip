@@ -76,7 +76,7 @@ __device__ __forceinline__ void rescore_range(const uint64_t* keys, uint64_t* tk
     }
 }
 
-__global__ __launch_bounds__(512) void select_i8_kernel(SelArgs sa) {
+__global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     const I8SelectArgs& p = sa.a;
     __shared__ uint64_t keys[KEY_CAP];
     __shared__ uint64_t tk[RS_CAP];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) void select_i8_kernel(SelArgs sa) {
     if (tid == 0) { s_total = 0; s_over = 0; s_cut = 0; s_t1 = 0ull; }
     __syncthreads();
     // ---- gather: one wave per chunk list
-    for (int c = wave; c < p.n_chunks; c += 8) {
+    for (int c = wave; c < p.n_chunks; c += (int)(blockDim.x >> 6)) {
         int n = p.cand_cnt[(size_t)c * p.b_pad + q];
         if (n > CAND_CAP) { n = CAND_CAP; if (lane == 0) s_over = 1; }       // the list overflowed: rows were dropped
         if (n <= 0) continue;
@@ -193,7 +193,8 @@ int launch_select_i8(const I8SelectArgs& a, hipStream_t stream) {
     sa.a = a;
     const float s0 = i8_scale_unit(a.K);
     sa.unit0 = s0 * s0;
-    hipLaunchKernelGGL(select_i8_kernel, dim3(a.B), dim3(512), 0, stream, sa);
+    // 16 waves per query: the 80 KiB of LDS admit two workgroups per CU, the re-score wants as many row fetches in flight as it can get
+    hipLaunchKernelGGL(select_i8_kernel, dim3(a.B), dim3(1024), 0, stream, sa);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

@@ -145,8 +145,8 @@ def test_rows_with_outlier_elements_zero_rows_and_partial_tile(ctx):
 
 
 def test_a_row_that_quantises_badly_switches_the_index_to_bf16(ctx):
-    """The int8 bound uses the LARGEST rounding residual of the index: one one-hot row (residual 0.07 at dim 1024 against
-    0.014 for Gaussian rows) would make every certificate fail and every query pay the int8 pass AND the bf16 pass.  The
+    """The int8 bound uses the LARGEST rounding residual of the index: one row dominated by a single element (residual ~0.05
+    at dim 1024 against 0.014 for Gaussian rows) would make every certificate fail and every query pay the int8 pass AND the bf16 pass.  The
     index notices (option i8_max_resid, default 0.02) and answers with the bf16 scan; overwriting the row brings int8 back."""
     rng = np.random.default_rng(61)
     d, n, b, k = 1024, 60_000, 300, 10
@@ -156,9 +156,9 @@ def test_a_row_that_quantises_badly_switches_the_index_to_bf16(ctx):
     idx.add(x)
     _, _, st = _check(ctx, idx, x, q, k)
     assert st["i8_collected"] > 0
-    onehot = np.zeros((1, d), np.float32)
-    onehot[0, 5] = 1.0
-    x2 = np.concatenate([x, onehot])
+    onehot = rng.standard_normal((1, d), dtype=np.float32)   # one element 40 x the others: its scale is set by that element and the
+    onehot[0, 5] = 40.0                                        #   other 1023 round at ~1/3 of their own size (an exact one-hot row would
+    x2 = np.concatenate([x, onehot])                           #   quantise perfectly: 127 and zeros)
     idx.add(onehot)
     _, _, st = _check(ctx, idx, x2, q, k, want_i8=False)
     assert st["i8_collected"] == 0                                        # the bf16 scan answered
@@ -236,3 +236,28 @@ def test_full_size_properties_int8():
     assert s8["uncertified"] <= 4 and s8["i8_overflows"] == 0, s8
     # the re-score reads a few hundred rows per query, the collection a couple of thousand keys
     assert s8["i8_rescored"] < 1024 * 1200 and s8["i8_collected"] < 1024 * 4000, s8
+
+
+def test_int8_first_pass_inside_a_device_group():
+    """The shards of a multi-device context are ordinary FLAT indexes: each runs the int8 first pass on its rows (options
+    set on the group index reach every shard), the [B,k] exchange and merge are unchanged, sqe_stats sums the members."""
+    from semantic_query_engine_amd import EXCHANGE_COPY, SCAN_INT8_RESCORE, Context, VectorIndex
+    ctx = Context(devices=[0, 0, 0], exchange=EXCHANGE_COPY)
+    rng = np.random.default_rng(71)
+    d, n, b, k = 256, 180_000, 300, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    plant = rng.integers(0, n, 100)
+    q[:100] = x[plant] + 0.1 * q[:100]
+    idx = VectorIndex(ctx, d)
+    for key, val in (("scan_mode", SCAN_INT8_RESCORE), ("i8_min_rows", 0), ("i8_sample_step", 4), ("i8_sample_m", 64)):
+        idx.set_option(key, val)
+    idx.add(x)
+    ctx.stats_reset()
+    cos, ids = idx.search(q, k)
+    st = ctx.stats()
+    ref_cos, ref_ids = exact_topk_fast(x, q, k)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, R.normalize_rows(x), R.normalize_rows(q))
+    assert np.array_equal(ids[:100, 0], plant)
+    assert st["i8_collected"] > 3 * b * 50, st               # all three shards collected
+    idx.close()

@@ -80,10 +80,10 @@ def test_multi_thread_build_under_thread_sanitizer():
     import subprocess
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(here, "oracle"), "tsan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    r = subprocess.run([os.path.join(here, "oracle", "_build", "hnsw_tsan"), "3000", "4", "3"], capture_output=True, text=True,
+    r = subprocess.run([os.path.join(here, "oracle", "_build", "hnsw_tsan"), "3000", "4", "1"], capture_output=True, text=True,
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=600)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-4000:])
-    assert r.stdout.strip() == "missed 0 of 1200 planted matches"
+    assert r.stdout.strip() == "missed 0 of 400 planted matches"
 
 
 def test_tiny_and_empty():

@@ -28,9 +28,8 @@ for blk in range((n + (1 << 20) - 1) >> 20):
     idx.add_device(x.data_ptr(), rows)
     ctx.synchronize()
     del x
-if args.scan_mode == "int8":
-    from semantic_query_engine_amd import SCAN_INT8_RESCORE
-    idx.set_option("scan_mode", SCAN_INT8_RESCORE)
+from semantic_query_engine_amd import SCAN_BF16_RESCORE, SCAN_INT8_RESCORE
+idx.set_option("scan_mode", SCAN_INT8_RESCORE if args.scan_mode == "int8" else SCAN_BF16_RESCORE)
 g = torch.Generator(device=dev).manual_seed(12345)
 q = torch.randn((b, D), generator=g, device=dev)
 cos = torch.empty((b, 10), device=dev); ids = torch.empty((b, 10), dtype=torch.int64, device=dev)
@@ -38,7 +37,6 @@ torch.cuda.synchronize()
 for _ in range(3):
     idx.search_device(q.data_ptr(), b, 10, cos.data_ptr(), ids.data_ptr())
 ctx.synchronize()
-ctx.stats_reset(); ctx.set_profiling(True)
 enq, tot = [], []
 for _ in range(args.iters):
     t0 = time.perf_counter()
@@ -47,14 +45,13 @@ for _ in range(args.iters):
     ctx.synchronize()
     t2 = time.perf_counter()
     enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
-st = ctx.stats()
-ctx.set_profiling(False)
-gpu_per_search = (st["scan_ms"] + st["prep_ms"] + st["select_ms"] + st.get("sample_ms", 0.0)) / args.iters
 enq.sort(); tot.sort()
+shard_step = tot[len(tot) // 2] / P            # the P shards of this one GPU run one after the other
 print(json.dumps({"shards": P, "rows": n, "rows_per_shard": n // P, "batch": b, "scan_mode": args.scan_mode,
                   "host_enqueue_ms_median": round(enq[len(enq) // 2], 4), "host_enqueue_ms_min": round(enq[0], 4),
                   "wall_ms_median_all_shards_on_one_gpu": round(tot[len(tot) // 2], 4),
-                  "gpu_ms_per_shard_step": round(gpu_per_search / P, 4),
-                  "host_enqueue_over_one_shard_step": round(enq[len(enq) // 2] / (gpu_per_search / P), 4),
-                  "note": "profiling events on (adds hipEventRecord pairs per stage to the enqueue time); on P real GPUs the shards' "
-                          "GPU time overlaps and the host enqueue time is the serial part"}))
+                  "ms_per_shard_step": round(shard_step, 4),
+                  "host_enqueue_over_one_shard_step": round(enq[len(enq) // 2] / shard_step, 4),
+                  "enqueue": "serial (r02)" if os.environ.get("SQE_GROUP_SERIAL") == "1" else "one worker thread per member",
+                  "note": "host_enqueue = wall time of sqe_index_search_device up to its return (nothing is synchronised); on P real GPUs "
+                          "the shards' GPU time overlaps and the host enqueue time is the serial part"}))

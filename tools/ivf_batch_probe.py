@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--sequence", default="", help="comma-separated batch sizes timed one after the other on the same index (r03: is a batch-1024 search slower after smaller ones?)")
 args = ap.parse_args()
 ctx = Context(0); dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(99)
@@ -25,7 +26,8 @@ ivf.train_device(xs.data_ptr(), n_s, iters=20, seed=0); ctx.synchronize(); del x
 gq = torch.Generator(device=dev).manual_seed(5)
 b = args.batch
 q = centres[torch.randint(0, 4096, (1024,), generator=gq, device=dev)] + 0.3 * torch.randn((1024, D), generator=gq, device=dev)
-ci = torch.empty((b, 10), device=dev); ji = torch.empty((b, 10), dtype=torch.int64, device=dev)
+ci = torch.empty((1024, 10), device=dev); ji = torch.empty((1024, 10), dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
-ms = timed(lambda: ivf.search_device(q.data_ptr(), b, 10, ci.data_ptr(), ji.data_ptr(), nprobe=32), ctx.synchronize, args.iters)
-print(json.dumps({"batch": b, "ivf_ms": round(ms, 4)}))
+for bb in ([int(v) for v in args.sequence.split(",")] if args.sequence else [b]):
+    ms = timed(lambda: ivf.search_device(q.data_ptr(), bb, 10, ci.data_ptr(), ji.data_ptr(), nprobe=32), ctx.synchronize, args.iters)
+    print(json.dumps({"batch": bb, "ivf_ms": round(ms, 4)}), flush=True)
