@@ -9,15 +9,22 @@ its own N rank processes (a child `python -m torch.distributed.run`, before anyt
 relays rank 0's JSON line and exits with the children's code.
 
 One "step" = one pass of the hot path over one batch of B synthetic queries that are
-already resident in HBM: sqe_index_search_device (query normalise + bf16 MFMA scan with
-fused top-k filter + fp32 rescore) and, for N > 1, the all-gather of per-shard top-k over
-RCCL plus the merge kernel.  The 10M-row index is sharded row-wise across the N ranks
-(strong scaling: the job is "answer B queries over the 10M-row index"; `--rows-per-gpu R` is the weak form of
-BASELINE.json's config 4, R rows on every rank, e.g. 8 x 10M = 80M rows).
+already resident in HBM: sqe_index_search_device (query normalise + first-pass scan + fp32
+re-score + exactness certificate + collect pass for uncertified queries) and, for N > 1, the
+all-gather of per-shard top-k over RCCL plus the merge kernel.  The first pass of the headline
+leg is the index's default, the int8 collect scan (--scan-mode int8: threshold pass on a row
+sample, v_mfma_i32_16x16x64_i8 scan of a per-tile-scaled int8 copy); a second leg of the same
+W + K steps runs the bf16 first pass on the same index and queries and is reported beside it
+(`bf16_scan`).  Both legs return the exact fp32 top-k (recall and max |dcos| against an
+independent torch fp32 scan are in the line).  The 10M-row index is sharded row-wise across
+the N ranks (strong scaling: the job is "answer B queries over the 10M-row index";
+`--rows-per-gpu R` is the weak form of BASELINE.json's config 4, R rows on every rank, e.g.
+8 x 10M = 80M rows).
 
-Rank 0 prints ONE JSON line (see the task contract); `roofline` is for the scan kernel
-(hipEvent-timed inside libsqe on the stream it runs on), `cpu_baseline` is the NumPy
-oracle (OpenBLAS sgemm + argpartition, all host cores) on a bounded sample.
+Rank 0 prints ONE JSON line (see the task contract); `roofline` is for the scan kernel of the
+headline leg (hipEvent-timed inside libsqe on the stream it runs on; `traffic` from the
+committed PMC passes of that kernel), `cpu_baseline` is the NumPy oracle (OpenBLAS sgemm +
+argpartition) on a bounded sample, `cpu_baseline_hnsw` the CPU HNSW the reference's index is.
 """
 from __future__ import annotations
 

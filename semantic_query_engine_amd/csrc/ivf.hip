@@ -456,6 +456,154 @@ __global__ __launch_bounds__(512) void ivf_list_scan_mfma_kernel(const bf16_t* _
     }
 }
 
+// int8 twin of the list scan (r03): the same tile, ring and LDS image -- a K step is 128 int8 elements = 128 B per row --
+// over a row-major int8 copy with per-row scales (quant.hip), v_mfma_i32_16x16x64_i8, half the bytes per probed row.  The
+// strips receive ESTIMATED cosines (acc x row scale x query scale); ivf_select_kernel re-scores the best of them in fp32
+// exactly as before.  IVF answers are approximate by nature (no certificate): the int8 estimate (error ~2e-3 at most on
+// Gaussian-like rows) only decides which kp = max(32, 4k) rows are re-scored.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+constexpr int LS_LDS_I8 = LS_NST * LS_STAGE + LS_SEG * 4 + LS_SEG * 4 + LS_Q * 4 + LS_Q * 4;
+static_assert(LS_LDS_I8 <= 160 * 1024, "LDS budget of the int8 list scan");
+
+__global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __restrict__ scan, int pitch, const uint32_t* __restrict__ sxi,
+                                                               const int8_t* __restrict__ qb, int qpitch, const uint32_t* __restrict__ sqi, float unit2,
+                                                                 const int* __restrict__ order,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 const int* __restrict__ lcount, const int* __restrict__ lq,
+                                                                 int cap, int nprobe, int K, int max_len,
+                                                                 float* __restrict__ pair_scores) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sorder = reinterpret_cast<int*>(smem + LS_NST * LS_STAGE);
+    float* sscale = reinterpret_cast<float*>(sorder + LS_SEG);     // [LS_SEG] row scales (sxi) of the segment's rows
+    int* spair = reinterpret_cast<int*>(sscale + LS_SEG);
+    float* sqscale = reinterpret_cast<float*>(spair + LS_Q);       // [LS_Q] unit^2 * sqi of the group's queries
+    const int L = blockIdx.x;
+    const int m = min(lcount[L], cap);
+    const int64_t off = offsets[L];
+    const int len_all = (int)(offsets[L + 1] - off);
+    if (m == 0 || len_all == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KS = K / 128;                        // 128 int8 elements = 128 B per row per K step: the bf16 kernel's LDS image
+    const char* scan_b = reinterpret_cast<const char*>(scan);
+    const char* qb_b = reinterpret_cast<const char*>(qb);
+    const int chunk_lo = lane & 7, r_in_piece = lane >> 3;
+
+    for (int seg0 = 0; seg0 < len_all; seg0 += LS_SEG) {
+        const int len = min(LS_SEG, len_all - seg0);
+        __syncthreads();
+        for (int i = tid; i < len; i += 512) {
+            const int r = order[off + seg0 + i];
+            sorder[i] = r;
+            sscale[i] = (float)sxi[r];
+        }
+        const int n_tiles = (len + LS_ROWS - 1) / LS_ROWS;
+        for (int g0 = 0; g0 < m; g0 += LS_Q) {
+            const int gq = min(LS_Q, m - g0);
+            __syncthreads();
+            if (tid < LS_Q) {
+                const int pr = lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
+                spair[tid] = pr;
+                sqscale[tid] = unit2 * (float)sqi[pr / nprobe];
+            }
+            __syncthreads();
+            // this lane's query row of the one Q piece its wave issues per stage
+            const int qj = wave * 8 + r_in_piece;
+            const size_t qoff = (size_t)(spair[qj] / nprobe) * qpitch + ((chunk_lo ^ ((qj >> 1) & 7)) << 4);
+
+            const int total = n_tiles * KS;
+            int i_tile = -1, i_ks = KS - 1;                 // issue cursor
+            size_t aoff[4];
+            auto issue = [&](int s) {
+                if (++i_ks == KS) {                         // the cursor enters a new tile: its rows' addresses
+                    i_ks = 0;
+                    ++i_tile;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int r = (wave + 8 * it) * 8 + r_in_piece;
+                        const int rr = min(i_tile * LS_ROWS + r, len - 1);          // rows past the end repeat the last one
+                        aoff[it] = (size_t)sorder[rr] * pitch + ((chunk_lo ^ ((r >> 1) & 7)) << 4);
+                    }
+                }
+                char* buf = smem + (s % LS_NST) * LS_STAGE;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) lds_dma16(scan_b + aoff[it] + (size_t)i_ks * 128, buf + (wave + 8 * it) * 1024);
+                lds_dma16(qb_b + qoff + (size_t)i_ks * 128, buf + LS_ROWS * 128 + wave * 1024);
+            };
+            for (int s = 0; s < LS_NST - 1 && s < total; ++s) issue(s);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+
+            i32x4_t acc[2][4];
+            int ks = 0, tile = 0;
+            for (int s = 0; s < total; ++s) {
+                const bool more = s + LS_NST - 1 < total;
+                if (more) issue(s + LS_NST - 1);
+                if (ks == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+                }
+                const char* tA = smem + (s % LS_NST) * LS_STAGE;
+                const char* tB = tA + LS_ROWS * 128;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    i32x4_t a[2], b[4];
+                    const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int r = wave * 32 + i * 16 + (lane & 15);
+                        a[i] = *reinterpret_cast<const i32x4_t*>(tA + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = j * 16 + (lane & 15);
+                        b[j] = *reinterpret_cast<const i32x4_t*>(tB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+                if (++ks == KS) {
+                    // scores of this tile: a lane holds 4 consecutive rows of one query per fragment
+                    // estimated cosines: acc * (sxi[row] unit) * (sqi[query] unit); the conversions are VALU instructions
+                    // hipcc sees (it pads the MFMA -> VALU distance), their results feed the asm store
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = j * 16 + (lane & 15);
+                        if (col < gq) {
+                            float* strip = pair_scores + (size_t)spair[col] * max_len + seg0 + tile * LS_ROWS;
+                            const float qs = sqscale[col];
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int r = wave * 32 + i * 16 + (lane >> 4) * 4;
+                                if (tile * LS_ROWS + r < len) {     // len and max_len are padded reads, not padded strips:
+                                    const f32x4 rs = *reinterpret_cast<const f32x4*>(sscale + tile * LS_ROWS + r);
+                                    f32x4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = (float)acc[i][j][e] * rs[e] * qs;
+                                    global_store_f4_asm(strip + r, v);
+                                }
+                            }
+                        }
+                    }
+                    ks = 0;
+                    ++tile;
+                }
+                if (more) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 // per query: the kp best scan scores over the strips of its probed lists, re-scored in fp32 against the
 // master, then the top-k by (fp32 cosine desc, row id asc)
 __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
@@ -660,6 +808,11 @@ struct IvfState {
     int64_t n_assigned = 0;            // rows of the base index that have an assignment
     int max_len = 0;
     Buf centroids, assign, order, offsets, counts, cursor;   // device
+    // int8 list scan (r03): row-major int8 copy of the base rows at i8_pitch bytes + per-row scales, filled lazily
+    Buf i8rows, i8sxi, q8, q8sqi;
+    int64_t i8_cap = 0, i8_done = 0;
+    int i8_pitch = 0;
+    bool use_i8 = true;              // knobs build: SQE_IVF_I8=0 keeps the bf16 list scan (A/B)
     Buf qn, qb, qd, cent_bf16, cscores, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
 };
@@ -772,6 +925,7 @@ int ivf_rows_updated(sqe_index* base, IvfState* st, const int64_t* rows_dev, int
     SQE_HIP(hipGetLastError());
     SQE_HIP(hipStreamSynchronize(s));                     // the temporaries die here
     st->lists_dirty = true;
+    st->i8_done = 0;                                      // the int8 copy is rebuilt from the master by the next search
     return SQE_OK;
 }
 
@@ -849,6 +1003,11 @@ int ivf_train(sqe_index* base, IvfState* st, const float* x_dev, int64_t n, int 
     return ivf_rows_added(base, st, s);
 }
 
+static bool ivf_i8_off() {
+    static const bool v = [] { const char* e = knob_env("SQE_IVF_I8"); return e && e[0] == '0'; }();   // knobs build only
+    return v;
+}
+
 int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, int nprobe, float* cos_out, int64_t* id_out,
                hipStream_t s) {
     if (!st->trained) return fail(SQE_ERR_STATE, "sqe_index_search: IVF index is not trained (sqe_index_train)");
@@ -892,6 +1051,41 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, base->master, st->qn.as<float>(), st->order.as<int>(),
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>());
+    } else if (st->use_i8 && dim >= 256 && dim % 128 == 0 && !ivf_i8_off()) {
+        // ---- int8 list scan: half the bytes per probed row.  The copy follows the base index lazily (rows appended since the
+        // last search are quantised here; an overwrite resets it: ivf_rows_updated).
+        const int64_t n = base->n.load();
+        const int p8 = dim + 128;
+        if (st->i8_cap < base->cap || st->i8_pitch != p8) {
+            Buf nr, ns;
+            SQE_TRY(nr.ensure((size_t)base->cap * p8));
+            SQE_TRY(ns.ensure((size_t)base->cap * 4));
+            if (st->i8_done > 0 && st->i8_pitch == p8) {
+                SQE_HIP(hipMemcpyAsync(nr.p, st->i8rows.p, (size_t)st->i8_done * p8, hipMemcpyDeviceToDevice, s));
+                SQE_HIP(hipMemcpyAsync(ns.p, st->i8sxi.p, (size_t)st->i8_done * 4, hipMemcpyDeviceToDevice, s));
+            } else {
+                st->i8_done = 0;
+            }
+            SQE_HIP(hipStreamSynchronize(s));
+            std::swap(nr.p, st->i8rows.p); std::swap(nr.bytes, st->i8rows.bytes);
+            std::swap(ns.p, st->i8sxi.p); std::swap(ns.bytes, st->i8sxi.bytes);
+            st->i8_cap = base->cap;
+            st->i8_pitch = p8;
+        }
+        for (int64_t lo = st->i8_done; lo < n; lo += (1 << 30)) {
+            const int m = (int)std::min<int64_t>(n - lo, 1 << 30);
+            SQE_TRY(launch_quantize_queries_i8(base->master + (size_t)lo * dim, m, dim, st->i8rows.as<int8_t>() + (size_t)lo * p8, p8,
+                                               st->i8sxi.as<uint32_t>() + lo, nullptr, s));
+        }
+        st->i8_done = n;
+        SQE_TRY(st->q8.ensure((size_t)(B + LS_Q) * p8));
+        SQE_TRY(st->q8sqi.ensure((size_t)(B + LS_Q) * 4));
+        SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));
+        const float unit = i8_scale_unit(dim);
+        SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
+        hipLaunchKernelGGL(ivf_list_scan_i8_kernel, dim3(nlist), dim3(512), LS_LDS_I8, s, st->i8rows.as<int8_t>(), p8, st->i8sxi.as<uint32_t>(),
+                           st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->order.as<int>(), st->offsets.as<int64_t>(),
+                           st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len, st->pair_scores.as<float>());
     } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel), LS_LDS));
         hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, base->scan, pitch, st->qb.as<bf16_t>(),
