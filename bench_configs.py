@@ -277,7 +277,7 @@ def mode_ivf(args, ctx, dev):
     del xn_host
     # ---- batch sweep (r02 verdict: the reference issues B = 1, main.py:355): IVF at 1 / 8 / 64 / 256 / 1024 of the same
     # queries (timed above).  Algorithmic bytes of a point: the rows of the DISTINCT lists its queries probe (from the exported
-    # assignment and the oracle's probe order on the exported centroids) x D x 2.
+    # assignment and the oracle's probe order on the exported centroids) x D x 1 byte (int8 list scan).
     sweep = []
     cen64 = centroids.astype(np.float64)
     list_len = np.bincount(assign, minlength=nlist)
@@ -288,7 +288,7 @@ def mode_ivf(args, ctx, dev):
         t_ivf = sweep_ms[bb]
         probes = np.argsort(-(qn_all[:bb] @ cen64.T), axis=1, kind="stable")[:, :nprobe]
         rows_touched = int(list_len[np.unique(probes)].sum())
-        by = rows_touched * D * 2
+        by = rows_touched * D * 1          # int8 list scan (r03): one byte per element of a probed row
         sweep.append({"batch": bb, "ivf_ms": round(t_ivf, 4), "ivf_qps": round(bb / t_ivf * 1e3), "rows_in_probed_lists": rows_touched,
                       "roofline": {"bound": "hbm", "achieved": round(by / t_ivf / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                    "frac": round(by / t_ivf / 1e6 / 8000.0, 4), "traffic": None, "algorithmic_bytes": by}})
@@ -296,7 +296,7 @@ def mode_ivf(args, ctx, dev):
     flat = build_clustered(ctx, args.rows, dev, centres, INDEX_FLAT, 0)
     cf = torch.empty((b, k), device=dev); jf = torch.empty((b, k), dtype=torch.int64, device=dev)
     flat_ms = timed(lambda: flat.search_device(q.data_ptr(), b, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
-    ivf_bytes = args.rows * D * 2                          # every list is probed at B = 1024: one read of the scan copy
+    ivf_bytes = args.rows * D * 1                          # every list is probed at B = 1024: one read of the int8 copy (r03; bf16 scan: x 2)
     for pt in sweep:                                       # the flat index at the same batch sizes (every query takes the collect pass here)
         bb = pt["batch"]
         t_flat = timed(lambda: flat.search_device(q.data_ptr(), bb, k, cf.data_ptr(), jf.data_ptr()), ctx.synchronize, 5)
