@@ -21,7 +21,9 @@
 //     exactly as the bf16 kernel does; a wave whose maxima reach a (conservative) threshold marks the tile, and the append
 //     path applies the exact predicate acc * s >= thr (the first r03 version scaled row by row: 128 v_mul_i32_i24 per wave
 //     and tile in a VALU-bound last phase);
-//   * marked tiles run the append path in one common phase (no cross-wave step follows it: no compaction exists);
+//   * a wave whose tile holds a survivor runs the append path: no cross-wave step follows (no compaction exists), so the
+//     appends need no phase of their own -- up to three query blocks they run on the wave's way into its next phase, from
+//     four on in a common phase behind a barrier (measured: tile_end);
 //   * the 256 row scales of a tile (1 KiB) arrive through one extra LDS-DMA piece per tile.
 #include <stdlib.h>
 
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         const int HS = P.HS;
         int j = 0;
         unsigned cols = 0;
+        const bool sync_appends = p.qblocks >= 4;      // appends in a common phase behind a barrier (tile_end)
         int* any_cols = flags + 8;
         int tile_scale = 1;                // the finished tile's scale (every row of a tile has the same: quant.hip)
         auto last_phase = [&](int e) {
@@ -382,12 +385,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
             int tlo[4];
             tile_thresholds(thr, tile_scale, tlo);
             cols = cmp_phase_last(acc, a, b, tlo);
-            if (cols != 0 && fresh_lane() == 0) *any_cols = 1;
+            if (sync_appends && cols != 0 && fresh_lane() == 0) *any_cols = 1;
         };
         // after the barrier that ends G1's last compute phase of entry e: every wave takes the same path
+        // Appends of a finished tile.  No cross-wave step follows them (no compaction, no shared flags), so they need no phase
+        // and no barrier of their own: a wave with survivors may simply enter its next phase late.  Measured (A/B in one
+        // gpurun call, profiles/r03_search/ab_append_barrier.log): without the barrier batch 256 -- one workgroup per DB chunk
+        // -- gains 3 % (2.63 -> 2.55 ms); batch 1024 -- four workgroups per chunk on one XCD -- loses 0.4 % (9.09 -> 9.13 ms):
+        // the common phase keeps the siblings' DB requests closer together.  So: a common phase from four query blocks on.
         auto tile_end = [&](int e) {
-            const bool any = __builtin_amdgcn_readfirstlane(*any_cols) != 0;
-            if (!any) return;
+            if (sync_appends) {
+                const bool any = __builtin_amdgcn_readfirstlane(*any_cols) != 0;
+                if (!any) return;
+            }
             if (cols) {
                 const int fl = fresh_lane();
                 const int64_t tile_row0 = (int64_t)(tile_begin + e) * SCAN_BM;
@@ -400,8 +410,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base);
             }
             __builtin_amdgcn_sched_barrier(0);
-            I8_BARRIER();
-            if (tid == 0) *any_cols = 0;       // read again a whole tile later
+            if (sync_appends) {
+                I8_BARRIER();
+                if (tid == 0) *any_cols = 0;       // read again a whole tile later
+            }
         };
         //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [append phase] | CMP(e+1,0) | MEM(e+1,1) ..
         //     G1: .. MEM(e,last) | CMP_LAST(e)| [append phase] | MEM(e+1,0) | CMP(e+1,0) ..
