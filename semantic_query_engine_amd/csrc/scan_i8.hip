@@ -21,9 +21,8 @@
 //     exactly as the bf16 kernel does; a wave whose maxima reach a (conservative) threshold marks the tile, and the append
 //     path applies the exact predicate acc * s >= thr (the first r03 version scaled row by row: 128 v_mul_i32_i24 per wave
 //     and tile in a VALU-bound last phase);
-//   * a wave whose tile holds a survivor runs the append path: no cross-wave step follows (no compaction exists), so the
-//     appends need no phase of their own -- up to three query blocks they run on the wave's way into its next phase, from
-//     four on in a common phase behind a barrier (measured: tile_end);
+//   * a wave whose tile holds a survivor runs the append path on its way into its next phase: no cross-wave step follows
+//     (no compaction exists), so the appends need neither a phase nor a barrier of their own (measured: tile_end);
 //   * the 256 row scales of a tile (1 KiB) arrive through one extra LDS-DMA piece per tile.
 #include <stdlib.h>
 
@@ -377,7 +376,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         const int HS = P.HS;
         int j = 0;
         unsigned cols = 0;
-        const bool sync_appends = p.qblocks >= 4;      // appends in a common phase behind a barrier (tile_end)
+        // knobs build, SQE_I8_SYNC=1: appends in a common phase behind a barrier, the r03a form (A/B; tile_end)
+        const bool sync_appends = p.dbg == 2;
         int* any_cols = flags + 8;
         int tile_scale = 1;                // the finished tile's scale (every row of a tile has the same: quant.hip)
         auto last_phase = [&](int e) {
@@ -389,10 +389,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         };
         // after the barrier that ends G1's last compute phase of entry e: every wave takes the same path
         // Appends of a finished tile.  No cross-wave step follows them (no compaction, no shared flags), so they need no phase
-        // and no barrier of their own: a wave with survivors may simply enter its next phase late.  Measured (A/B in one
-        // gpurun call, profiles/r03_search/ab_append_barrier.log): without the barrier batch 256 -- one workgroup per DB chunk
-        // -- gains 3 % (2.63 -> 2.55 ms); batch 1024 -- four workgroups per chunk on one XCD -- loses 0.4 % (9.09 -> 9.13 ms):
-        // the common phase keeps the siblings' DB requests closer together.  So: a common phase from four query blocks on.
+        // and no barrier of their own: a wave with survivors simply enters its next phase late.  Measured against the common
+        // phase behind a barrier that the bf16 kernel needs for its compaction (profiles/r03_search/ab_append_barrier.log):
+        // batch 256 -3 %, 768 -1.2 %, 512 and 1024 within +-0.4 %.
         auto tile_end = [&](int e) {
             if (sync_appends) {
                 const bool any = __builtin_amdgcn_readfirstlane(*any_cols) != 0;
@@ -655,7 +654,11 @@ int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
     I8KernelArgs k;
     k.db8 = a.db8; k.tile_stride = a.tile_stride; k.sxi = a.sxi; k.q8 = a.q8; k.q_pitch = a.q_pitch; k.thr_int = a.thr_int;
     k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = a.b_pad; k.n_tiles = a.n_tiles; k.n_chunks = a.n_chunks; k.qblocks = a.qblocks;
-    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.dbg = 0;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt;
+    {
+        static const int force = [] { const char* e = knob_env("SQE_I8_SYNC"); return e ? (e[0] == '0' ? 1 : 2) : 0; }();   // knobs build only
+        k.dbg = force;
+    }
     if (a.bn == 64) return launch_small<8, 1, 2, 4, 3, 3>(k, stream);          // the tilings of scan.hip's 64- / 128-query kernels
     if (a.bn == 128) return launch_small<4, 2, 4, 4, 3, 2>(k, stream);
     auto kern = scan_i8_pp_kernel;
