@@ -162,6 +162,15 @@ def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
     x = rng.standard_normal((sample_rows, D), dtype=np.float32)
     q = rng.standard_normal((b, D), dtype=np.float32)
     xn = R.normalize_rows(x)
+    # the box gives one GPU's job a share of the host (16 CPUs): OpenBLAS sized to the machine's
+    # 256 hardware threads oversubscribes that share and runs several times slower
+    threads = max(1, min(int(os.environ.get("SQE_CPU_THREADS", "16")), len(os.sched_getaffinity(0))))
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter = None
+        threads = os.cpu_count() or 1
     t0 = time.perf_counter()
     qn = R.normalize_rows(q)
     blk = 65536
@@ -179,11 +188,8 @@ def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
             o = np.argpartition(-v, k, axis=1)[:, :k]
             best = (np.take_along_axis(v, o, 1), np.take_along_axis(i, o, 1))
     dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    if limiter is not None:
+        limiter.restore_original_limits()
     qps = b / (dt * (n_total / sample_rows))
     return {"value": round(qps, 3), "unit": "queries/s", "cores": int(threads), "kind": "port",
             "sample": f"numpy oracle (fp32 sgemm + argpartition top-{k}), {sample_rows} rows x {b} queries "
