@@ -441,6 +441,13 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
 // vmcnt(40), which leaves them in flight together with the two younger half-steps of DMA (vmcnt retires in
 // issue order).
 namespace gpp {
+// Ablation builds of the ping-pong GEMM (make KNOBS=1 GPP_ABLATE=<bits>, timing only, results wrong): 8 = no DMA pieces,
+// 16 = no operand reads, 32 = no epilogue, 64 = every tile reads the operands of tile 0 (always in L2).  Compile-time, so
+// that the shipped kernel's register allocation is the one measured (run-time switches made hipcc spill).
+#ifndef SQE_GPP_ABLATE
+#define SQE_GPP_ABLATE 0
+#endif
+constexpr int GPP_ABLATE = SQE_GPP_ABLATE;
 constexpr int HALF_K = 32, LINE_BYTES = 128, OPER_BYTES = 128 * LINE_BYTES, STAGE_BYTES = 2 * OPER_BYTES, NSTAGE = 4;
 constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;      // 128 KiB
 constexpr int MAX_BIAS_N = 4096;                      // the bias vector sits in LDS behind the ring
@@ -547,7 +554,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     }
     auto seat = [&](Cursor& c) {                      // operand tiles of entry c.e
         const int t = tile_at(c.e);
-        const int nt = t % p.n_tiles, tt = t / p.n_tiles;
+        int nt = t % p.n_tiles, tt = t / p.n_tiles;
+        if (GPP_ABLATE & 64) nt = tt = 0;
         c.a = reinterpret_cast<const char*>(p.W) + (size_t)nt * 256 * ld;
         c.b = reinterpret_cast<const char*>(p.X) + (size_t)tt * 256 * ld;
     };
@@ -574,6 +582,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     f32x4 acc[8][4];
     AOps a;
     BOps b;
+    if (GPP_ABLATE & 16) {                            // (the MFMAs then compute on these)
+        for (int i = 0; i < 8; ++i) a[i] = bf16x8{};
+        for (int i = 0; i < 4; ++i) b[i] = bf16x8{};
+    }
     // waves 0, 1 (4, 5) of a group issue their DMA pieces first and read their operands after, waves 2, 3 (6, 7) the
     // other way round: the address unit and the LDS then work side by side (scan_pp.hip: dma_and_reads)
     const bool reads_first = p.pp_stagger && ((wave >> 1) & 1);
@@ -586,12 +598,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     };
     auto mem_phase = [&](int j) {
         const bool more = j + 3 < J;
+        const bool do_dma = more && !(GPP_ABLATE & 8);
+        constexpr bool do_reads = !(GPP_ABLATE & 16);
         if (reads_first) {
-            read_operands(j);
-            if (more) issue(dm, (j + 3) & 3);
+            if (do_reads) read_operands(j);
+            if (do_dma) issue(dm, (j + 3) & 3);
         } else {
-            if (more) issue(dm, (j + 3) & 3);
-            read_operands(j);
+            if (do_dma) issue(dm, (j + 3) & 3);
+            if (do_reads) read_operands(j);
         }
         // retire the DMA of half-step j + 1; j + 2 and j + 3 stay in flight, and so do the 16 epilogue stores for
         // the two memory phases after an epilogue (they are younger than the half-step that has to land)
@@ -603,6 +617,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         if (more) advance(dm);
     };
     auto epilogue = [&](int e) {
+        if ((GPP_ABLATE & 32) && p.K > 0) return;         // (a run-time condition: the MFMAs stay)
         const int t = tile_at(e);
         const int nt = t % p.n_tiles, tt = t / p.n_tiles;
         const int n0 = nt * 256, t0 = tt * 256;
