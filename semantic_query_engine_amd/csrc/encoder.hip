@@ -441,17 +441,21 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
 // vmcnt(40), which leaves them in flight together with the two younger half-steps of DMA (vmcnt retires in
 // issue order).
 namespace gpp {
-// Ablation builds of the ping-pong GEMM (make KNOBS=1 GPP_ABLATE=<bits>, timing only, results wrong): 8 = no DMA pieces,
-// 16 = no operand reads, 32 = no epilogue, 64 = every tile reads the operands of tile 0 (always in L2).  Compile-time, so
+// Ablation builds of the ping-pong GEMM (tools/build_gpp_ablate.sh <bits>, timing only, results wrong): 8 = no DMA pieces,
+// 16 = no operand reads, 32 = no epilogue, 64 = every tile reads the operands of tile 0 (always in L2), 128 = the pieces of a
+// half-step read whole 128-B lines of 128 rows instead of 64-B halves of 256 rows (the same bytes per tile), 256 = a 5-stage
+// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it.  Compile-time, so
 // that the shipped kernel's register allocation is the one measured (run-time switches made hipcc spill).
 #ifndef SQE_GPP_ABLATE
 #define SQE_GPP_ABLATE 0
 #endif
 constexpr int GPP_ABLATE = SQE_GPP_ABLATE;
-constexpr int HALF_K = 32, LINE_BYTES = 128, OPER_BYTES = 128 * LINE_BYTES, STAGE_BYTES = 2 * OPER_BYTES, NSTAGE = 4;
+constexpr int HALF_K = 32, LINE_BYTES = 128, OPER_BYTES = 128 * LINE_BYTES, STAGE_BYTES = 2 * OPER_BYTES;
+constexpr int NSTAGE = (GPP_ABLATE & 256) ? 5 : 4;   // (ablation 256: a 5-stage ring over ALL of the LDS, the bias vector inside it)
+constexpr int AHEAD = NSTAGE - 1;                     // half-steps of DMA in flight
 constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;      // 128 KiB
 constexpr int MAX_BIAS_N = 4096;                      // the bias vector sits in LDS behind the ring
-constexpr int LDS_BYTES = RING_BYTES + MAX_BIAS_N * 4;
+constexpr int LDS_BYTES = (GPP_ABLATE & 256) ? RING_BYTES : RING_BYTES + MAX_BIAS_N * 4;
 typedef bf16x8 AOps[8];
 typedef bf16x8 BOps[4];
 struct Cursor { int e, h; const char* a; const char* b; };
@@ -502,7 +506,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     using namespace gpp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* bias_lds = reinterpret_cast<float*>(smem + RING_BYTES);
+    float* bias_lds = reinterpret_cast<float*>(smem + ((GPP_ABLATE & 256) ? 0 : RING_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2, wm = wave >> 2, wn = wave & 3;
@@ -548,6 +552,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         };
         offA0 = (unsigned)(wrow(row) * ld) + (c & 3) * 16;
         offA1 = (unsigned)(wrow(row + 64) * ld) + (c & 3) * 16;
+        if (GPP_ABLATE & 128) {                       // whole 128-B lines: 8 lanes per row, 128 rows per half-step
+            off0 = offA0 = (unsigned)(line * ld) + c * 16;
+            off1 = offA1 = off0 + (unsigned)(64 * ld);
+        }
         const int r = lane & 15, cq = lane >> 4, sw = (r >> 1) & 7;
         rdA = (unsigned)(r * LINE_BYTES + (((wm * 4 + cq) ^ sw) << 4));
         rdB = (unsigned)(((wn & 1) * 64 + r) * LINE_BYTES + ((((wn >> 1) * 4 + cq) ^ sw) << 4));
@@ -567,8 +575,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     };
     auto issue = [&](const Cursor& c, int stage) {
         char* st = smem + stage * STAGE_BYTES;
-        const char* as = c.a + c.h * (HALF_K * 2);
-        const char* bs = c.b + c.h * (HALF_K * 2);
+        size_t koff = (size_t)c.h * (HALF_K * 2);
+        if (GPP_ABLATE & 128) {                       // (rows 0-127 over all of K, then rows 128-255: the tile's bytes, each once)
+            const size_t hh = (size_t)c.h * 128;
+            koff = hh % ld + hh / ld * 128 * ld;
+        }
+        const char* as = c.a + koff;
+        const char* bs = c.b + koff;
         glds16(as + offA0, st + wave * 1024);
         glds16(as + offA1, st + (wave + 8) * 1024);
         glds16(bs + off0, st + OPER_BYTES + wave * 1024);
@@ -590,28 +603,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     // other way round: the address unit and the LDS then work side by side (scan_pp.hip: dma_and_reads)
     const bool reads_first = p.pp_stagger && ((wave >> 1) & 1);
     auto read_operands = [&](int j) {
-        const char* st = smem + (j & 3) * STAGE_BYTES;
+        const char* st = smem + (NSTAGE == 4 ? (j & 3) : j % NSTAGE) * STAGE_BYTES;
 #pragma unroll
         for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const bf16x8*>(st + rdA + fm * 2048);
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const bf16x8*>(st + OPER_BYTES + rdB + fn * 2048);
     };
     auto mem_phase = [&](int j) {
-        const bool more = j + 3 < J;
+        const bool more = j + AHEAD < J;
         const bool do_dma = more && !(GPP_ABLATE & 8);
         constexpr bool do_reads = !(GPP_ABLATE & 16);
         if (reads_first) {
             if (do_reads) read_operands(j);
-            if (do_dma) issue(dm, (j + 3) & 3);
+            if (do_dma) issue(dm, NSTAGE == 4 ? ((j + 3) & 3) : (j + AHEAD) % NSTAGE);
         } else {
-            if (do_dma) issue(dm, (j + 3) & 3);
+            if (do_dma) issue(dm, NSTAGE == 4 ? ((j + 3) & 3) : (j + AHEAD) % NSTAGE);
             if (do_reads) read_operands(j);
         }
         // retire the DMA of half-step j + 1; j + 2 and j + 3 stay in flight, and so do the 16 epilogue stores for
         // the two memory phases after an epilogue (they are younger than the half-step that has to land)
         if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (post_epi > 0) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (post_epi > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(16 + 4 * (AHEAD - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (AHEAD - 1)) : "memory");
         if (post_epi > 0) --post_epi;
         advance(rd);
         if (more) advance(dm);
@@ -687,13 +700,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
                 }
             }
         }
-        post_epi = 2;
+        post_epi = AHEAD - 1;
         __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- the bias vector into LDS (N <= MAX_BIAS_N: the launcher checks), then the prologue: half-steps 0, 1, 2
-    for (int i = tid * 4; i < p.N; i += 512 * 4) *reinterpret_cast<float4*>(bias_lds + i) = *reinterpret_cast<const float4*>(p.bias + i);
-    for (int s = 0; s < 3 && s < J; ++s) {
+    if (!(GPP_ABLATE & 256))
+        for (int i = tid * 4; i < p.N; i += 512 * 4) *reinterpret_cast<float4*>(bias_lds + i) = *reinterpret_cast<const float4*>(p.bias + i);
+    for (int s = 0; s < AHEAD && s < J; ++s) {
         issue(dm, s);
         advance(dm);
     }
