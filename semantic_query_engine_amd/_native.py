@@ -100,6 +100,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C semantic_query_engine_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    # A PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  If libsqe.so pulls in the system
+    # copies first and torch is imported later, the process holds two HIP runtimes and torch's finds no device
+    # (hipErrorNoDevice at its first CUDA call).  With torch loaded first the dynamic linker binds libsqe.so to the
+    # copies already in the process (same SONAMEs).  Nothing of torch is used here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

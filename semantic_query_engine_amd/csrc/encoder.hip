@@ -427,24 +427,31 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
     return SQE_OK;
 }
 
-// Large-batch form, ping-pong schedule (the schedule of the flat scan, scan_pp.hip, with an epilogue where the
-// scan has its filter): 256 x 256 tiles, PERSISTENT workgroups, K in 32-wide half-steps through a 4-stage LDS
-// ring (three half-steps of DMA in flight instead of the one 64-wide step of gemm_persistent_kernel), the
-// two waves of a SIMD alternating between a compute phase (32 MFMAs on registers) and a memory phase (LDS-DMA
-// issue, 12 ds_read_b128), one s_barrier per phase.  G0 (waves 0-3) runs one phase ahead of G1 (waves 4-7):
-//     G0: .. CMP(e,last) | EPI(e) MEM(e+1,0) | CMP(e+1,0)        | MEM(e+1,1) ..
-//     G1: .. MEM(e,last) | CMP(e,last)       | EPI(e) MEM(e+1,0) | CMP(e+1,0) ..
-// A group's epilogue (VALU + stores) runs beside the OTHER group's compute phase, at the head of its own next
-// memory phase, when its operand registers are dead (no spills) -- the 8-wave epilogue of gemm_persistent_kernel
-// runs with the matrix pipe idle.  The first compute phase of a tile takes a zero C operand (no VALU clears).
-// The epilogue's 32 stores per wave are fire-and-forget: the memory phase it shares and the next one wait with
-// vmcnt(40), which leaves them in flight together with the two younger half-steps of DMA (vmcnt retires in
-// issue order).
+// Large-batch form, ping-pong schedule (the flat scan's, scan_pp.hip, with an epilogue where the scan has its
+// filter): 256 x 256 tiles, PERSISTENT workgroups, K in 32-wide half-steps through a 4-stage LDS ring, the two
+// waves of a SIMD taking turns at the matrix pipe: while one computes a half-step (32 MFMAs on registers) the
+// other does its memory work (4 LDS-DMA pieces, 12 ds_read_b128).  r03: ONE s_barrier per half-step (period T_j)
+// instead of one per phase -- the two groups no longer wait for each other in the middle of a period, so a period
+// costs a wave's compute part plus its memory part (about 1,300 cycles) instead of twice the longer of the two
+// (about 1,700):
+//     G0 (waves 0-3), T_j: compute j | [epilogue] wait for its pieces of j + 1, read operands j + 1, issue pieces j + 3 | barrier
+//     G1 (waves 4-7), T_j: [epilogue] read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier
+// What a period reads was waited for by its owner before the barrier that opens the period (G1's pieces of j + 1 at the
+// end of T_{j-1}, G0's pieces of j inside T_{j-1}); the stage a period's pieces go to, (j + 3) & 3, held half-step
+// j - 1, last read before that barrier too (by G0 inside T_{j-2}, by G1 at the head of T_{j-1}).  A wave keeps at
+// most two half-steps of pieces in flight: a counted vmcnt(4) retires the older one (vmcnt(20) while the 16 stores
+// of an epilogue are younger than it: two waits of G0, one of G1).  In wall time the change is worth less than in
+// cycles (QKV GEMM 365 k -> 328 k cycles, the encode of 64 x 512 tokens 23.9 -> 23.5 ms): the chip gives clock back.
+// A group's epilogue (VALU + stores) runs beside the OTHER group's compute part, when its operand registers are
+// dead (no spills) -- the 8-wave epilogue of gemm_persistent_kernel runs with the matrix pipe idle.  The first
+// compute part of a tile takes a zero C operand (no VALU clears).  The r02 form (two barriers per half-step, three
+// half-steps in flight) stays as ablation build 512.
 namespace gpp {
 // Ablation builds of the ping-pong GEMM (tools/build_gpp_ablate.sh <bits>, timing only, results wrong): 8 = no DMA pieces,
 // 16 = no operand reads, 32 = no epilogue, 64 = every tile reads the operands of tile 0 (always in L2), 128 = the pieces of a
 // half-step read whole 128-B lines of 128 rows instead of 64-B halves of 256 rows (the same bytes per tile), 256 = a 5-stage
-// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it.  Compile-time, so
+// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it (with 512 only); 512 = r02's schedule,
+// a barrier after every phase (results right).  Compile-time, so
 // that the shipped kernel's register allocation is the one measured (run-time switches made hipcc spill).
 #ifndef SQE_GPP_ABLATE
 #define SQE_GPP_ABLATE 0
@@ -719,7 +726,96 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     unsigned long long k0 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, c0 = 0, c1 = 0, c2 = 0, clk[8] = {};
 #endif
     GPP_STAMP(k0);
-    if (group == 0) {
+    if (!(GPP_ABLATE & 512)) {
+        // one barrier per half-step (the schedule in the comment above the kernel)
+        auto issue_next = [&](int jj) {
+            if (jj + 3 < J && !(GPP_ABLATE & 8)) {
+                issue(dm, (jj + 3) & 3);
+                advance(dm);
+            }
+        };
+        auto wait_pieces = [&](bool younger_in_flight) {     // all of this wave's pieces but its youngest half-step have landed
+            if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (post_epi > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (post_epi > 0) --post_epi;
+        };
+        auto g0_mem = [&](int jj) {                          // after computing half-step jj
+            if (jj + 1 < J) {
+                wait_pieces(jj + 2 < J);
+                if (reads_first) {
+                    read_operands(jj + 1);
+                    issue_next(jj);
+                } else {
+                    issue_next(jj);
+                    read_operands(jj + 1);
+                }
+            }
+        };
+        auto g1_mem = [&](int jj) {                          // before computing half-step jj
+            if (reads_first) {
+                read_operands(jj);
+                issue_next(jj);
+            } else {
+                issue_next(jj);
+                read_operands(jj);
+            }
+        };
+        auto g1_wait = [&](int jj) {                         // after computing half-step jj: its pieces of jj + 2
+            if (jj + 2 < J) wait_pieces(jj + 3 < J);
+        };
+        if (group == 0) {
+            read_operands(0);
+            for (int e = 0; e < my_tiles; ++e) {
+                cmp_phase<true>(acc, a, b);
+                g0_mem(j);
+                GPP_BARRIER();
+                ++j;
+                for (int h = 1; h < HS - 1; ++h) {
+                    // (stamps of this form: [3] memory part, [4] barrier, [5] compute part, per steady period)
+                    GPP_STAMP(c0);
+                    cmp_phase<false>(acc, a, b);
+                    GPP_STAMP(c1);
+                    g0_mem(j);
+                    GPP_STAMP(c2);
+                    GPP_BARRIER();
+                    GPP_STAMP(t0);
+                    GPP_ACC(clk[5] += c1 - c0; clk[3] += c2 - c1; clk[4] += t0 - c2; ++clk[7]; ++clk[0]);
+                    ++j;
+                }
+                cmp_phase<false>(acc, a, b);
+                epilogue(e);                                 // (post_epi = 2: its stores are younger than the next two waits' pieces)
+                g0_mem(j);
+                GPP_BARRIER();
+                ++j;
+            }
+        } else {
+            for (int e = 0; e < my_tiles; ++e) {
+                if (e > 0) {
+                    epilogue(e - 1);
+                    post_epi = 1;                            // younger than this period's wait only
+                }
+                g1_mem(j);
+                cmp_phase<true>(acc, a, b);
+                g1_wait(j);
+                GPP_BARRIER();
+                ++j;
+                for (int h = 1; h < HS; ++h) {
+                    GPP_STAMP(c0);
+                    g1_mem(j);
+                    GPP_STAMP(c1);
+                    cmp_phase<false>(acc, a, b);
+                    GPP_STAMP(c2);
+                    g1_wait(j);
+                    GPP_BARRIER();
+                    GPP_STAMP(t0);
+                    GPP_ACC(clk[3] += c1 - c0; clk[5] += c2 - c1; clk[4] += t0 - c2; ++clk[7]; ++clk[0]);
+                    ++j;
+                }
+            }
+            epilogue(my_tiles - 1);
+        }
+    } else if (group == 0) {
         mem_phase(0);
         GPP_BARRIER();
         for (int e = 0; e < my_tiles; ++e) {

@@ -414,6 +414,91 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (tid == 0) *any_cols = 0;       // read again a whole tile later
             }
         };
+#ifndef SQE_I8_TWO_BARRIERS
+        // ONE barrier per half-step (period T_j; encoder.hip's gemm_pp_kernel has the derivation):
+        //     G0, T_j: compute j | wait for its pieces of j + 1, read operands j + 1, issue pieces j + 3 | barrier | [appends]
+        //     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [appends]
+        // What a period reads was waited for by its owner before the barrier that opens it; the stage its pieces go to held
+        // half-step j - 1, last read before that barrier too.  A wave keeps at most two half-steps of pieces in flight, the
+        // counted vmcnt(4) retires the older one; wave 0's scale piece and a wave's appended keys are extra YOUNGER entries of
+        // the queue at worst, which only makes a wait retire more.
+        auto issue_next = [&](int jj) {
+            if (jj + 3 < P.J) {
+                P.issue(P.dm, (jj + 3) & 3, true);
+                P.advance(P.dm);
+            }
+        };
+        auto wait_pieces = [&](bool younger_in_flight) {
+            if (younger_in_flight) I8_WAIT(0x0F74);          // vmcnt(4)
+            else I8_WAIT(0x0F70);                            // vmcnt(0)
+        };
+        auto g0_mem = [&](int jj) {                          // after computing half-step jj
+            if (jj + 1 < P.J) {
+                wait_pieces(jj + 2 < P.J);
+                if (P.order == 0) {
+                    issue_next(jj);
+                    read_operands(P, a, b, jj + 1);
+                } else {
+                    read_operands(P, a, b, jj + 1);
+                    issue_next(jj);
+                }
+            }
+        };
+        auto g1_mem = [&](int jj) {                          // before computing half-step jj
+            if (P.order == 0) {
+                issue_next(jj);
+                read_operands(P, a, b, jj);
+            } else {
+                read_operands(P, a, b, jj);
+                issue_next(jj);
+            }
+        };
+        auto g1_wait = [&](int jj) {                         // after computing half-step jj: its pieces of jj + 2
+            if (jj + 2 < P.J) wait_pieces(jj + 3 < P.J);
+        };
+        if (group == 0) {
+            read_operands(P, a, b, 0);
+            for (int e = 0; e < P.nt; ++e) {
+                cmp_phase<true>(acc, a, b);
+                g0_mem(j);
+                I8_BARRIER();
+                ++j;
+                for (int h = 1; h < HS - 1; ++h) {
+                    cmp_phase<false>(acc, a, b);
+                    g0_mem(j);
+                    I8_BARRIER();
+                    ++j;
+                }
+                last_phase(e);
+                g0_mem(j);
+                I8_BARRIER();
+                ++j;
+                tile_end(e);
+            }
+        } else {
+            for (int e = 0; e < P.nt; ++e) {
+                g1_mem(j);
+                cmp_phase<true>(acc, a, b);
+                g1_wait(j);
+                I8_BARRIER();
+                ++j;
+                for (int h = 1; h < HS - 1; ++h) {
+                    g1_mem(j);
+                    cmp_phase<false>(acc, a, b);
+                    g1_wait(j);
+                    I8_BARRIER();
+                    ++j;
+                }
+                g1_mem(j);
+                last_phase(e);
+                g1_wait(j);
+                I8_BARRIER();
+                ++j;
+                tile_end(e);
+            }
+        }
+#else
+        // r03a schedule, a barrier after every phase (A/B: tools/build_variant.sh scan_i8 -DSQE_I8_TWO_BARRIERS):
         //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [append phase] | CMP(e+1,0) | MEM(e+1,1) ..
         //     G1: .. MEM(e,last) | CMP_LAST(e)| [append phase] | MEM(e+1,0) | CMP(e+1,0) ..
         if (group == 0) {
@@ -462,6 +547,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 tile_end(e);
             }
         }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
