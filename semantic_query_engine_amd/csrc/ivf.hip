@@ -457,7 +457,8 @@ __global__ __launch_bounds__(512) void ivf_list_scan_mfma_kernel(const bf16_t* _
 }
 
 // int8 twin of the list scan (r03): the same tile, ring and LDS image -- a K step is 128 int8 elements = 128 B per row --
-// over a row-major int8 copy with per-row scales (quant.hip), v_mfma_i32_16x16x64_i8, half the bytes per probed row.  The
+// over an int8 copy with per-row scales (quant.hip) kept in LIST order (row p of the copy is row order[p] of the index, so a list
+// is one contiguous run of rows: a stream, where the bf16 kernel gathers rows by id), v_mfma_i32_16x16x64_i8, half the bytes per probed row.  The
 // strips receive ESTIMATED cosines (acc x row scale x query scale); ivf_select_kernel re-scores the best of them in fp32
 // exactly as before.  IVF answers are approximate by nature (no certificate): the int8 estimate (error ~2e-3 at most on
 // Gaussian-like rows) only decides which kp = max(32, 4k) rows are re-scored.
@@ -492,11 +493,7 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
     for (int seg0 = 0; seg0 < len_all; seg0 += LS_SEG) {
         const int len = min(LS_SEG, len_all - seg0);
         __syncthreads();
-        for (int i = tid; i < len; i += 512) {
-            const int r = order[off + seg0 + i];
-            sorder[i] = r;
-            sscale[i] = (float)sxi[r];
-        }
+        for (int i = tid; i < len; i += 512) sscale[i] = (float)sxi[off + seg0 + i];     // (the copy is in list order: no ids needed)
         const int n_tiles = (len + LS_ROWS - 1) / LS_ROWS;
         for (int g0 = 0; g0 < m; g0 += LS_Q) {
             const int gq = min(LS_Q, m - g0);
@@ -522,7 +519,7 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
                     for (int it = 0; it < 4; ++it) {
                         const int r = (wave + 8 * it) * 8 + r_in_piece;
                         const int rr = min(i_tile * LS_ROWS + r, len - 1);          // rows past the end repeat the last one
-                        aoff[it] = (size_t)sorder[rr] * pitch + ((chunk_lo ^ ((r >> 1) & 7)) << 4);
+                        aoff[it] = (size_t)(off + seg0 + rr) * pitch + ((chunk_lo ^ ((r >> 1) & 7)) << 4);
                     }
                 }
                 char* buf = smem + (s % LS_NST) * LS_STAGE;
@@ -808,7 +805,7 @@ struct IvfState {
     int64_t n_assigned = 0;            // rows of the base index that have an assignment
     int max_len = 0;
     Buf centroids, assign, order, offsets, counts, cursor;   // device
-    // int8 list scan (r03): row-major int8 copy of the base rows at i8_pitch bytes + per-row scales, filled lazily
+    // int8 list scan (r03): int8 copy of the base rows IN LIST ORDER at i8_pitch bytes + per-row scales, (re)built lazily
     Buf i8rows, i8sxi, q8, q8sqi;
     int64_t i8_cap = 0, i8_done = 0;
     int i8_pitch = 0;
@@ -954,6 +951,7 @@ static int ivf_build_lists(sqe_index* base, IvfState* st, hipStream_t s) {
     SQE_HIP(hipGetLastError());
     SQE_HIP(hipStreamSynchronize(s));
     st->lists_dirty = false;
+    st->i8_done = 0;                                      // the int8 copy follows the list order
     return SQE_OK;
 }
 
@@ -1052,32 +1050,23 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>());
     } else if (st->use_i8 && dim >= 256 && dim % 128 == 0 && !ivf_i8_off()) {
-        // ---- int8 list scan: half the bytes per probed row.  The copy follows the base index lazily (rows appended since the
-        // last search are quantised here; an overwrite resets it: ivf_rows_updated).
-        const int64_t n = base->n.load();
+        // ---- int8 list scan: half the bytes per probed row, and the rows of a list contiguous.  The copy is in list order, so it
+        // is rebuilt from the master whenever the lists were (rows added, rows overwritten): ivf_build_lists / ivf_rows_updated
+        // reset i8_done.  ~12 ms per 10 M rows, on the first search after the change.
+        const int64_t n = st->n_assigned;
         const int p8 = dim + 128;
-        if (st->i8_cap < base->cap || st->i8_pitch != p8) {
-            Buf nr, ns;
-            SQE_TRY(nr.ensure((size_t)base->cap * p8));
-            SQE_TRY(ns.ensure((size_t)base->cap * 4));
-            if (st->i8_done > 0 && st->i8_pitch == p8) {
-                SQE_HIP(hipMemcpyAsync(nr.p, st->i8rows.p, (size_t)st->i8_done * p8, hipMemcpyDeviceToDevice, s));
-                SQE_HIP(hipMemcpyAsync(ns.p, st->i8sxi.p, (size_t)st->i8_done * 4, hipMemcpyDeviceToDevice, s));
-            } else {
-                st->i8_done = 0;
-            }
-            SQE_HIP(hipStreamSynchronize(s));
-            std::swap(nr.p, st->i8rows.p); std::swap(nr.bytes, st->i8rows.bytes);
-            std::swap(ns.p, st->i8sxi.p); std::swap(ns.bytes, st->i8sxi.bytes);
-            st->i8_cap = base->cap;
+        if (st->i8_cap < n || st->i8_pitch != p8) {
+            const int64_t cap = std::max<int64_t>(base->cap, n);
+            SQE_TRY(st->i8rows.ensure((size_t)cap * p8));
+            SQE_TRY(st->i8sxi.ensure((size_t)cap * 4));
+            st->i8_cap = cap;
             st->i8_pitch = p8;
+            st->i8_done = 0;
         }
-        for (int64_t lo = st->i8_done; lo < n; lo += (1 << 30)) {
-            const int m = (int)std::min<int64_t>(n - lo, 1 << 30);
-            SQE_TRY(launch_quantize_queries_i8(base->master + (size_t)lo * dim, m, dim, st->i8rows.as<int8_t>() + (size_t)lo * p8, p8,
-                                               st->i8sxi.as<uint32_t>() + lo, nullptr, s));
+        if (st->i8_done != n) {
+            SQE_TRY(launch_quantize_gather_i8(base->master, st->order.as<int>(), n, dim, st->i8rows.as<int8_t>(), p8, st->i8sxi.as<uint32_t>(), s));
+            st->i8_done = n;
         }
-        st->i8_done = n;
         SQE_TRY(st->q8.ensure((size_t)(B + LS_Q) * p8));
         SQE_TRY(st->q8sqi.ensure((size_t)(B + LS_Q) * 4));
         SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));

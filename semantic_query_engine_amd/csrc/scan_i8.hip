@@ -377,7 +377,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         int j = 0;
         unsigned cols = 0;
         // knobs build, SQE_I8_SYNC=1: appends in a common phase behind a barrier, the r03a form (A/B; tile_end)
-        const bool sync_appends = p.dbg == 2;
+        const bool sync_appends = (p.dbg & 7) == 2;
         int* any_cols = flags + 8;
         int tile_scale = 1;                // the finished tile's scale (every row of a tile has the same: quant.hip)
         auto last_phase = [&](int e) {
@@ -432,8 +432,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
             if (younger_in_flight) I8_WAIT(0x0F74);          // vmcnt(4)
             else I8_WAIT(0x0F70);                            // vmcnt(0)
         };
+#ifdef SQE_DEBUG_KNOBS
+        // SQE_I8_DBG (knobs build, A/B of this schedule; profiles/r03_search/ab_one_barrier_variants.log): 1 every wave
+        // pieces-then-reads (+0.1 %), 2 every wave reads-then-pieces (+1.5 %), 4 NO raised priority while computing (+1.0 %), 8 G0
+        // issues its pieces before it waits, three half-steps in flight (+-0.3 %), 16 appends before the barrier (-0.2 %)
+        const int xdbg = p.dbg >> 3;
+        if (xdbg & 1) P.order = 0;
+        if (xdbg & 2) P.order = 1;
+#define I8_PRIO(n) do { if (!(xdbg & 4)) __builtin_amdgcn_s_setprio(n); } while (0)
+#else
+        constexpr int xdbg = 0;
+        // a wave's compute part runs at raised priority: when both waves of a SIMD have instructions ready, the MFMAs go first
+#define I8_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
         auto g0_mem = [&](int jj) {                          // after computing half-step jj
             if (jj + 1 < P.J) {
+                if (xdbg & 8) {
+                    issue_next(jj);
+                    if (jj + 3 < P.J) I8_WAIT(0x0F78);       // vmcnt(8)
+                    else wait_pieces(jj + 2 < P.J);
+                    read_operands(P, a, b, jj + 1);
+                    return;
+                }
                 wait_pieces(jj + 2 < P.J);
                 if (P.order == 0) {
                     issue_next(jj);
@@ -459,44 +479,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         if (group == 0) {
             read_operands(P, a, b, 0);
             for (int e = 0; e < P.nt; ++e) {
+                I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
+                I8_PRIO(0);
                 g0_mem(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
+                    I8_PRIO(2);
                     cmp_phase<false>(acc, a, b);
+                    I8_PRIO(0);
                     g0_mem(j);
                     I8_BARRIER();
                     ++j;
                 }
+                I8_PRIO(2);
                 last_phase(e);
+                I8_PRIO(0);
                 g0_mem(j);
+                if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                tile_end(e);
+                if (!(xdbg & 16)) tile_end(e);
             }
         } else {
             for (int e = 0; e < P.nt; ++e) {
                 g1_mem(j);
+                I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
+                I8_PRIO(0);
                 g1_wait(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
                     g1_mem(j);
+                    I8_PRIO(2);
                     cmp_phase<false>(acc, a, b);
+                    I8_PRIO(0);
                     g1_wait(j);
                     I8_BARRIER();
                     ++j;
                 }
                 g1_mem(j);
+                I8_PRIO(2);
                 last_phase(e);
+                I8_PRIO(0);
                 g1_wait(j);
+                if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                tile_end(e);
+                if (!(xdbg & 16)) tile_end(e);
             }
         }
+#undef I8_PRIO
 #else
         // r03a schedule, a barrier after every phase (A/B: tools/build_variant.sh scan_i8 -DSQE_I8_TWO_BARRIERS):
         //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [append phase] | CMP(e+1,0) | MEM(e+1,1) ..
@@ -743,7 +778,8 @@ int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
     k.cand = a.cand; k.cand_cnt = a.cand_cnt;
     {
         static const int force = [] { const char* e = knob_env("SQE_I8_SYNC"); return e ? (e[0] == '0' ? 1 : 2) : 0; }();   // knobs build only
-        k.dbg = force;
+        static const int xdbg = [] { const char* e = knob_env("SQE_I8_DBG"); return e ? atoi(e) : 0; }();
+        k.dbg = force | (xdbg << 3);
     }
     if (a.bn == 64) return launch_small<8, 1, 2, 4, 3, 3>(k, stream);          // the tilings of scan.hip's 64- / 128-query kernels
     if (a.bn == 128) return launch_small<4, 2, 4, 4, 3, 2>(k, stream);

@@ -464,6 +464,70 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 }
 #endif
 
+// r03 experiment, ONE barrier per half-step (period T_j; derivation: encoder.hip, gemm_pp_kernel; shipped in scan_i8.hip):
+//     G0, T_j: compute j | wait for its pieces of j + 1, read operands j + 1, issue pieces j + 3 | barrier | [tile end]
+//     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [tile end]
+// A wave keeps at most two half-steps of pieces in flight; its counted vmcnt(4) retires the older one.  Bound-table
+// pieces (two per wave and fetch) enter the queue in FRONT of the half-step issued with them, so the next wait retires
+// them too -- a period later; appended keys likewise.  The memory part that reads half-step x (and issues x + ahead:
+// 2 in G0, 3 in G1) does the bound work mem_phase() does, on the same schedule in x; a fetch follows the last one by at
+// least FIVE half-steps here: the fold (at + 3) of a G1 wave opens a period, a G0 wave's fetch at + 4 would leave from
+// the middle of that same period with no barrier in between.
+// Measured against the shipped schedule below (tools/r03_exp21.sh, profiles/r03_search/ab_one_barrier_bf16.log): batch 1024
+// 18.21 -> 17.86 ms, 512 equal, 256 +1-2 % -- the bf16 scan gives the cycles back as clock (the int8 scan and its 9 % do not), so
+// this form is built with -DSQE_PP_ONE_BARRIER only (tools/build_variant.sh scan_pp 1bar -DSQE_PP_ONE_BARRIER).
+#if !defined(SQE_PHASE_STAMPS) && defined(SQE_PP_ONE_BARRIER)
+#define PP_WAIT_VM4() PP_WAIT(0x0F74)
+#define PP_WAIT_VM0() PP_WAIT(0x0F70)
+__device__ __forceinline__ void mem_part(PP& P, const Filter& f, AOps& a, BOps& b, int x, int ahead, bool wait_first) {
+    const bool more = x + ahead < P.J && !P.no_dma;
+    const bool general = x >= P.lean_until;
+    if (general && P.refresh_pending >= 0 && x >= P.refresh_j + 3) {
+        if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.gshift_k, P.k_rows, fresh_lane());
+        P.refresh_pending = -1;
+    }
+    if (wait_first) {                                    // G0: this wave's pieces of half-step x
+        if (x + 1 < P.J) PP_WAIT_VM4();
+        else PP_WAIT_VM0();
+    }
+    if (general && P.bound_on && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && x >= P.refresh_j + 5) {
+        const bool want = P.rd.e == 1 ? (P.rd.h >= P.HS / 4 && P.refresh_ctr < NSLICEP)
+                                      : (P.rd.e <= P.e_fast ? (P.rd.h & P.refresh_mask) == 0
+                                                            : (P.rd.h == 0 && (P.rd.e <= P.e_mid || (P.rd.e & P.late_mask) == 0)));
+        if (want) {
+            P.refresh_pending = P.refresh_ctr % NSLICEP;
+            ++P.refresh_ctr;
+            P.refresh_j = x;
+            refresh_issue<true>(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
+        }
+    }
+    const int stage = (x + ahead) & 3;
+    if (P.order == 0) {
+        if (more) P.issue(P.dm, stage);
+        read_operands(P, a, b, x);
+    } else {
+        read_operands(P, a, b, x);
+        if (more) P.issue(P.dm, stage);
+    }
+    if (general) {                                       // first half-step that needs the general form again (mem_phase())
+        int next;
+        if (P.refresh_pending >= 0) next = max(x + 1, P.refresh_j + 3);
+        else if (!P.bound_on || P.no_filter) next = P.J;
+        else if (P.rd.e == 0) next = P.HS + P.HS / 4;
+        else if (P.rd.e == 1) next = P.refresh_ctr < NSLICEP ? max(max(x + 1, P.refresh_j + 5), P.HS + P.HS / 4) : 2 * P.HS;
+        else if (P.rd.e <= P.e_fast) next = max(x + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask)), P.refresh_j + 5);
+        else {
+            int e2 = P.rd.e + 1;
+            if (e2 > P.e_mid) e2 = (e2 + P.late_mask) & ~P.late_mask;
+            next = e2 * P.HS;
+        }
+        P.lean_until = P.no_dma ? 0 : next;
+    }
+    P.advance(P.rd);
+    if (more) P.advance(P.dm);
+}
+#endif
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -604,6 +668,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     __syncthreads();                       // prologue landed, state initialised
 
     {
+        // the shipped schedule, a barrier after every phase (the one-barrier experiment is above mem_part()):
         //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [SLOW(e) sync] | CMP(e+1,0) | MEM(e+1,1) ..
         //     G1: .. MEM(e,last) | CMP_LAST(e)| [SLOW(e) sync] | MEM(e+1,0) | CMP(e+1,0) ..
         if (P.J > 0) {
@@ -644,6 +709,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 PP_STAMP(e4);
                 PP_ACC(pclk.te[0] += e1 - e0; pclk.te[1] += e2 - e1; pclk.te[2] += e3 - e2; pclk.te[3] += e4 - e3; pclk.te[4] += (cols != 0); ++pclk.te[5]);
             };
+#if !defined(SQE_PHASE_STAMPS) && defined(SQE_PP_ONE_BARRIER)
+            auto g1_wait = [&](int jj) {                     // after computing half-step jj: this wave's pieces of jj + 2
+                if (jj + 2 < P.J) {
+                    if (jj + 3 < P.J) PP_WAIT_VM4();
+                    else PP_WAIT_VM0();
+                }
+            };
+            if (group == 0) {
+                read_operands(P, a, b, 0);
+                P.advance(P.rd);
+                for (int e = 0; e < n_entries; ++e) {
+                    if (!P.no_mma) cmp_phase<true>(acc, a, b);
+                    mem_part(P, f, a, b, j + 1, 2, true);
+                    if (HS == 2) load_thr();
+                    PP_BARRIER();
+                    ++j;
+                    for (int h = 1; h < HS - 1; ++h) {
+                        if (!P.no_mma) cmp_phase<false>(acc, a, b);
+                        mem_part(P, f, a, b, j + 1, 2, true);
+                        if (h == HS - 2) load_thr();
+                        PP_BARRIER();
+                        ++j;
+                    }
+                    last_phase();
+                    if (e + 1 < n_entries) mem_part(P, f, a, b, j + 1, 2, true);
+                    PP_BARRIER();
+                    ++j;
+                    if (e + 1 < n_entries) tile_end(e);
+                }
+            } else {
+                for (int e = 0; e < n_entries; ++e) {
+                    mem_part(P, f, a, b, j, 3, false);
+                    if (!P.no_mma) cmp_phase<true>(acc, a, b);
+                    g1_wait(j);
+                    PP_BARRIER();
+                    ++j;
+                    for (int h = 1; h < HS - 1; ++h) {
+                        mem_part(P, f, a, b, j, 3, false);
+                        if (!P.no_mma) cmp_phase<false>(acc, a, b);
+                        g1_wait(j);
+                        PP_BARRIER();
+                        ++j;
+                    }
+                    mem_part(P, f, a, b, j, 3, false);
+                    load_thr();
+                    last_phase();
+                    g1_wait(j);
+                    PP_BARRIER();
+                    ++j;
+                    if (e + 1 < n_entries) tile_end(e);
+                }
+            }
+#else
             if (group == 0) {
                 mem_phase(P, f, a, b, 0);
                 PP_BARRIER();
@@ -747,6 +865,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     PP_ACC(if (f.dbg_counters && tid == 0 && (e == 100 || e == 400)) f.dbg_counters[512 + blockIdx.x * 2 + (e == 400)] = wall_clock64());
                 }
             }
+#endif
 #ifdef SQE_PHASE_STAMPS
             if (f.dbg_counters && (blockIdx.x == 0 || blockIdx.x == 100) && lane == 0) {
                 unsigned long long* o = f.dbg_counters + 8 + (blockIdx.x ? 64 : 0) + P.wave * 8;
