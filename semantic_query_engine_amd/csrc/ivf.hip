@@ -102,13 +102,18 @@ __global__ void ivf_count_kernel(const int* __restrict__ assign, int64_t n, int*
     if (i < n && assign[i] >= 0) atomicAdd(counts + assign[i], 1);
 }
 
+// order[p] = the row at position p of the list-ordered sequence; dpos[p] = its row in the int8 copy, where every list starts
+// on a 256-row tile (tile_off: tiles in front of each list)
 __global__ void ivf_scatter_kernel(const int* __restrict__ assign, int64_t n, const int64_t* __restrict__ offsets,
-                                   int* __restrict__ cursor, int* __restrict__ order) {
+                                   const int64_t* __restrict__ tile_off, int* __restrict__ cursor, int* __restrict__ order,
+                                   int* __restrict__ dpos) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int a = assign[i];
     if (a < 0) return;
-    order[offsets[a] + atomicAdd(cursor + a, 1)] = (int)i;
+    const int c = atomicAdd(cursor + a, 1);
+    order[offsets[a] + c] = (int)i;
+    dpos[offsets[a] + c] = (int)(tile_off[a] * 256 + c);
 }
 
 // top-nprobe lists of a query from its dense coarse scores [nlist] (score desc, list id asc); one workgroup
@@ -457,8 +462,9 @@ __global__ __launch_bounds__(512) void ivf_list_scan_mfma_kernel(const bf16_t* _
 }
 
 // int8 twin of the list scan (r03): the same tile, ring and LDS image -- a K step is 128 int8 elements = 128 B per row --
-// over an int8 copy with per-row scales (quant.hip) kept in LIST order (row p of the copy is row order[p] of the index, so a list
-// is one contiguous run of rows: a stream, where the bf16 kernel gathers rows by id), v_mfma_i32_16x16x64_i8, half the bytes per probed row.  The
+// over an int8 copy with per-row scales (quant.hip) kept in LIST order: every list is a run of whole 256-row tiles in the flat scan's
+// tiled layout (64-B K slices, 16 KiB apart), so a K step of a tile is 32 contiguous KiB -- a stream, where the bf16 kernel gathers rows
+// by id, 128 B at a time -- v_mfma_i32_16x16x64_i8, half the bytes per probed row.  The
 // strips receive ESTIMATED cosines (acc x row scale x query scale); ivf_select_kernel re-scores the best of them in fp32
 // exactly as before.  IVF answers are approximate by nature (no certificate): the int8 estimate (error ~2e-3 at most on
 // Gaussian-like rows) only decides which kp = max(32, 4k) rows are re-scored.
@@ -466,9 +472,9 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 constexpr int LS_LDS_I8 = LS_NST * LS_STAGE + LS_SEG * 4 + LS_SEG * 4 + LS_Q * 4 + LS_Q * 4;
 static_assert(LS_LDS_I8 <= 160 * 1024, "LDS budget of the int8 list scan");
 
-__global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __restrict__ scan, int pitch, const uint32_t* __restrict__ sxi,
+__global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __restrict__ scan, int64_t tile_stride, const uint32_t* __restrict__ sxi,
                                                                const int8_t* __restrict__ qb, int qpitch, const uint32_t* __restrict__ sqi, float unit2,
-                                                                 const int* __restrict__ order,
+                                                                 const int64_t* __restrict__ tile_off,
                                                                  const int64_t* __restrict__ offsets,
                                                                  const int* __restrict__ lcount, const int* __restrict__ lq,
                                                                  int cap, int nprobe, int K, int max_len,
@@ -493,7 +499,8 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
     for (int seg0 = 0; seg0 < len_all; seg0 += LS_SEG) {
         const int len = min(LS_SEG, len_all - seg0);
         __syncthreads();
-        for (int i = tid; i < len; i += 512) sscale[i] = (float)sxi[off + seg0 + i];     // (the copy is in list order: no ids needed)
+        const int64_t tile0 = tile_off[L] + seg0 / LS_ROWS;                        // first tile of the segment in the copy
+        for (int i = tid; i < len; i += 512) sscale[i] = (float)sxi[tile0 * LS_ROWS + i];
         const int n_tiles = (len + LS_ROWS - 1) / LS_ROWS;
         for (int g0 = 0; g0 < m; g0 += LS_Q) {
             const int gq = min(LS_Q, m - g0);
@@ -518,13 +525,15 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int r = (wave + 8 * it) * 8 + r_in_piece;
-                        const int rr = min(i_tile * LS_ROWS + r, len - 1);          // rows past the end repeat the last one
-                        aoff[it] = (size_t)(off + seg0 + rr) * pitch + ((chunk_lo ^ ((r >> 1) & 7)) << 4);
+                        const int rr = min(i_tile * LS_ROWS + r, len - 1) - i_tile * LS_ROWS;   // rows past the end repeat the last one (same tile)
+                        // the lane's 16 bytes of a K step: chunk c of the row's 128 B = bytes (c & 3) * 16 of its 64-B slice 2 ks + (c >> 2)
+                        const int c = chunk_lo ^ ((r >> 1) & 7);
+                        aoff[it] = (size_t)(tile0 + i_tile) * tile_stride + (size_t)(c >> 2) * 16384 + rr * 64 + (c & 3) * 16;
                     }
                 }
                 char* buf = smem + (s % LS_NST) * LS_STAGE;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) lds_dma16(scan_b + aoff[it] + (size_t)i_ks * 128, buf + (wave + 8 * it) * 1024);
+                for (int it = 0; it < 4; ++it) lds_dma16(scan_b + aoff[it] + (size_t)i_ks * 32768, buf + (wave + 8 * it) * 1024);
                 lds_dma16(qb_b + qoff + (size_t)i_ks * 128, buf + LS_ROWS * 128 + wave * 1024);
             };
             for (int s = 0; s < LS_NST - 1 && s < total; ++s) issue(s);
@@ -806,9 +815,9 @@ struct IvfState {
     int max_len = 0;
     Buf centroids, assign, order, offsets, counts, cursor;   // device
     // int8 list scan (r03): int8 copy of the base rows IN LIST ORDER at i8_pitch bytes + per-row scales, (re)built lazily
-    Buf i8rows, i8sxi, q8, q8sqi;
-    int64_t i8_cap = 0, i8_done = 0;
-    int i8_pitch = 0;
+    Buf i8rows, i8sxi, q8, q8sqi, tile_off, dpos;
+    int64_t i8_cap = 0, i8_done = 0, total_tiles = 0;    // i8_cap: tiles allocated
+    int64_t i8_tile_stride = 0;
     bool use_i8 = true;              // knobs build: SQE_IVF_I8=0 keeps the bf16 list scan (A/B)
     Buf qn, qb, qd, cent_bf16, cscores, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
@@ -946,8 +955,16 @@ static int ivf_build_lists(sqe_index* base, IvfState* st, hipStream_t s) {
         st->max_len = std::max(st->max_len, h_counts[i]);
     }
     SQE_HIP(hipMemcpyAsync(st->offsets.p, st->h_offsets.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
+    std::vector<int64_t> h_tile_off(nlist + 1, 0);
+    for (int i = 0; i < nlist; ++i) h_tile_off[i + 1] = h_tile_off[i] + (h_counts[i] + 255) / 256;
+    st->total_tiles = h_tile_off[nlist];
+    if (st->total_tiles * 256 > 0x7fffffffLL) return fail(SQE_ERR_INVALID, "ivf: too many rows for one index shard");
+    SQE_TRY(st->tile_off.ensure((size_t)(nlist + 1) * 8));
+    SQE_TRY(st->dpos.ensure((size_t)std::max<int64_t>(n, 1) * 4));
+    SQE_HIP(hipMemcpyAsync(st->tile_off.p, h_tile_off.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
     if (n > 0) hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st->assign.as<int>(), n,
-                                  st->offsets.as<int64_t>(), st->cursor.as<int>(), st->order.as<int>());
+                                  st->offsets.as<int64_t>(), st->tile_off.as<int64_t>(), st->cursor.as<int>(), st->order.as<int>(),
+                                  st->dpos.as<int>());
     SQE_HIP(hipGetLastError());
     SQE_HIP(hipStreamSynchronize(s));
     st->lists_dirty = false;
@@ -1050,21 +1067,24 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>());
     } else if (st->use_i8 && dim >= 256 && dim % 128 == 0 && !ivf_i8_off()) {
-        // ---- int8 list scan: half the bytes per probed row, and the rows of a list contiguous.  The copy is in list order, so it
-        // is rebuilt from the master whenever the lists were (rows added, rows overwritten): ivf_build_lists / ivf_rows_updated
-        // reset i8_done.  ~12 ms per 10 M rows, on the first search after the change.
+        // ---- int8 list scan: half the bytes per probed row, every list a run of whole 256-row tiles in the flat scan's tiled
+        // layout (a K step of a tile is 32 contiguous KiB).  The copy is in list order, so it is rebuilt from the master whenever
+        // the lists were (rows added, rows overwritten): ivf_build_lists / ivf_rows_updated reset i8_done.  ~12 ms per 10 M rows,
+        // on the first search after the change.
         const int64_t n = st->n_assigned;
-        const int p8 = dim + 128;
-        if (st->i8_cap < n || st->i8_pitch != p8) {
-            const int64_t cap = std::max<int64_t>(base->cap, n);
-            SQE_TRY(st->i8rows.ensure((size_t)cap * p8));
-            SQE_TRY(st->i8sxi.ensure((size_t)cap * 4));
+        const int p8 = dim + 128;                          // (pitch of the quantised QUERY rows)
+        const int64_t tile_stride = (int64_t)(dim / 64) * 16384 + 2048;
+        if (st->i8_cap < st->total_tiles || st->i8_tile_stride != tile_stride) {
+            const int64_t cap = std::max<int64_t>(st->total_tiles, (base->cap + 255) / 256 + nlist);
+            SQE_TRY(st->i8rows.ensure((size_t)cap * tile_stride));
+            SQE_TRY(st->i8sxi.ensure((size_t)cap * 256 * 4));
             st->i8_cap = cap;
-            st->i8_pitch = p8;
+            st->i8_tile_stride = tile_stride;
             st->i8_done = 0;
         }
         if (st->i8_done != n) {
-            SQE_TRY(launch_quantize_gather_i8(base->master, st->order.as<int>(), n, dim, st->i8rows.as<int8_t>(), p8, st->i8sxi.as<uint32_t>(), s));
+            SQE_TRY(launch_quantize_gather_i8(base->master, st->order.as<int>(), st->dpos.as<int>(), n, dim, st->i8rows.as<int8_t>(), tile_stride,
+                                              st->i8sxi.as<uint32_t>(), s));
             st->i8_done = n;
         }
         SQE_TRY(st->q8.ensure((size_t)(B + LS_Q) * p8));
@@ -1072,8 +1092,8 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));
         const float unit = i8_scale_unit(dim);
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
-        hipLaunchKernelGGL(ivf_list_scan_i8_kernel, dim3(nlist), dim3(512), LS_LDS_I8, s, st->i8rows.as<int8_t>(), p8, st->i8sxi.as<uint32_t>(),
-                           st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->order.as<int>(), st->offsets.as<int64_t>(),
+        hipLaunchKernelGGL(ivf_list_scan_i8_kernel, dim3(nlist), dim3(512), LS_LDS_I8, s, st->i8rows.as<int8_t>(), tile_stride, st->i8sxi.as<uint32_t>(),
+                           st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(),
                            st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len, st->pair_scores.as<float>());
     } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel), LS_LDS));

@@ -100,7 +100,8 @@ int launch_quantize_rows_i8(const float* master, const int64_t* rows, int64_t fi
                             int64_t tile_stride, uint32_t* sxi, uint32_t* resid_max, hipStream_t stream);
 // int8 copy of normalised query rows, row-major at q_pitch bytes; sqi[q], resid_rows[q]
 int launch_quantize_queries_i8(const float* qn, int B, int dim, int8_t* out, int q_pitch, uint32_t* sqi, float* resid_rows, hipStream_t stream);
-int launch_quantize_gather_i8(const float* x, const int* gather, int64_t n, int dim, int8_t* out, int pitch, uint32_t* sxi, hipStream_t stream);
+int launch_quantize_gather_i8(const float* x, const int* gather, const int* scatter, int64_t n, int dim, int8_t* out, int64_t tile_stride,
+                              uint32_t* sxi, hipStream_t stream);
 // collect thresholds from the sample pass: tau[q] = cos_s[q][m - 1] (true cosines, best first)
 int launch_i8_thresholds(const float* cos_s, int m, const uint32_t* sqi, int dim, int B, int b_pad, int* thr_int, float* thr_eff,
                          hipStream_t stream);

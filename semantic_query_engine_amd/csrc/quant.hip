@@ -34,16 +34,18 @@ template <bool TILED>
 __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const float* __restrict__ x, const int64_t* __restrict__ rows, int64_t first_row,
                                                                int64_t n, int dim, float s0, int8_t* __restrict__ out, int64_t tile_stride,
                                                                int q_pitch, uint32_t* __restrict__ sxi_out, float* __restrict__ resid_rows,
-                                                               uint32_t* __restrict__ resid_max, const int* __restrict__ gather = nullptr) {
+                                                               uint32_t* __restrict__ resid_max, const int* __restrict__ gather = nullptr,
+                                                               const int* __restrict__ scatter = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int nvec = dim >> 2;
     float wave_resid = 0.f;
     for (int64_t i = wave0; i < n; i += nwaves) {
-        const int64_t row = rows ? rows[i] : first_row + i;
-        // gather: output row `row` is input row gather[row] (the IVF copy in list order)
-        const float4* src = reinterpret_cast<const float4*>(x + (gather ? (int64_t)gather[row] : row) * (int64_t)dim);
+        const int64_t in_row = rows ? rows[i] : first_row + i;
+        // gather / scatter (the IVF copy in list order): input row gather[i], output row scatter[i]
+        const int64_t row = scatter ? (int64_t)scatter[in_row] : in_row;
+        const float4* src = reinterpret_cast<const float4*>(x + (gather ? (int64_t)gather[in_row] : in_row) * (int64_t)dim);
         float mx = 0.f, ss = 0.f;
         for (int v = lane; v < nvec; v += 64) {
             const float4 u = src[v];
@@ -218,13 +220,15 @@ int launch_quantize_queries_i8(const float* qn, int B, int dim, int8_t* out, int
     return SQE_OK;
 }
 
-// out row p = quantised x row gather[p], p in [0, n): the IVF index's int8 copy in LIST order (ivf.hip)
-int launch_quantize_gather_i8(const float* x, const int* gather, int64_t n, int dim, int8_t* out, int pitch, uint32_t* sxi, hipStream_t stream) {
+// The IVF index's int8 copy (ivf.hip): output row scatter[p] = quantised x row gather[p], p in [0, n), per-row scales, in the flat
+// scan's TILED layout (256-row tiles of tile_stride bytes, the 64-B K slice h of tile row r at h * 16 KiB + r * 64)
+int launch_quantize_gather_i8(const float* x, const int* gather, const int* scatter, int64_t n, int dim, int8_t* out, int64_t tile_stride,
+                              uint32_t* sxi, hipStream_t stream) {
     if (n <= 0) return SQE_OK;
-    if (dim % 64 != 0 || dim > 8192 || pitch < dim || pitch % 16 != 0) return fail(SQE_ERR_INVALID, "int8 rows: bad dim / pitch");
+    if (dim % 64 != 0 || dim > 8192) return fail(SQE_ERR_INVALID, "int8 rows: bad dim");
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 3) / 4, 1 << 20);
-    hipLaunchKernelGGL((quantize_rows_i8_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, (const int64_t*)nullptr, (int64_t)0, n, dim,
-                       i8_scale_unit(dim), out, (int64_t)0, pitch, sxi, (float*)nullptr, (uint32_t*)nullptr, gather);
+    hipLaunchKernelGGL((quantize_rows_i8_kernel<true>), dim3(blocks), dim3(256), 0, stream, x, (const int64_t*)nullptr, (int64_t)0, n, dim,
+                       i8_scale_unit(dim), out, tile_stride, 0, sxi, (float*)nullptr, (uint32_t*)nullptr, gather, scatter);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# IVF int8 copy in list order: IVF tests, then config 5 (bench_configs --mode ivf); then the int8 scan variants again (exp22: 0 4 20)
+# IVF int8 copy in tiled list order: IVF tests, config 5 (bench_configs --mode ivf), the batch sequence probe
 set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/r03_exp23
@@ -13,4 +13,4 @@ d=json.load(open("$out/cfg_ivf.json"))
 print("ivf_ms", d["ivf_ms"], "qps", d["ivf_qps"], "recall", d["recall_at_10_vs_exact"], "parity", d["parity_vs_oracle_ivf"])
 for pt in d["batch_sweep"]: print(pt["batch"], pt["ivf_ms"], pt["roofline"]["frac"])
 PY
-bash tools/r03_exp22.sh 0 4 20 > $out/exp22.log 2>&1; grep "^libsqe" $out/exp22.log | awk '{print $2, $4, $8, $NF, $(NF-2)}' | sort
+python tools/ivf_batch_probe.py --sequence > $out/ivf_seq.jsonl 2> $out/ivf_seq.err; cut -c1-200 $out/ivf_seq.jsonl
