@@ -13,4 +13,4 @@ d=json.load(open("$out/cfg_ivf.json"))
 print("ivf_ms", d["ivf_ms"], "qps", d["ivf_qps"], "recall", d["recall_at_10_vs_exact"], "parity", d["parity_vs_oracle_ivf"])
 for pt in d["batch_sweep"]: print(pt["batch"], pt["ivf_ms"], pt["roofline"]["frac"])
 PY
-python tools/ivf_batch_probe.py --sequence > $out/ivf_seq.jsonl 2> $out/ivf_seq.err; cut -c1-200 $out/ivf_seq.jsonl
+python tools/ivf_batch_probe.py --sequence 1024,1,8,64,256,1024 > $out/ivf_seq.jsonl 2> $out/ivf_seq.err; cut -c1-200 $out/ivf_seq.jsonl
