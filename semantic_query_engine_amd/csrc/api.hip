@@ -643,6 +643,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             I8SelectArgs sa;
             sa.cand = idx->cand.as<uint64_t>(); sa.cand_cnt = idx->cand_cnt.as<int>(); sa.n_chunks = plan.n_chunks; sa.b_pad = plan.b_pad;
             sa.master = idx->master; sa.qn = idx->qn.as<float>(); sa.K = K; sa.B = B; sa.k = k;
+            sa.scan16 = idx->scan; sa.pitch16 = idx->pitch;
             sa.sxi = idx->i8sxi.as<uint32_t>(); sa.sqi = idx->q8sqi.as<uint32_t>();
             sa.q_resid8 = idx->q8resid.as<float>(); sa.db_resid8_max = idx->i8resid_max.as<uint32_t>();
             sa.q_resid16 = idx->q_resid.as<float>(); sa.db_resid16_max = idx->resid_max.as<uint32_t>();

@@ -119,6 +119,7 @@ int launch_scan_i8(const I8ScanArgs& args, hipStream_t stream);
 struct I8SelectArgs {
     const uint64_t* cand; const int* cand_cnt; int n_chunks, b_pad;
     const float* master; const float* qn; int K, B, k;
+    const bf16_t* scan16; int pitch16;                        // the bf16 scan copy (rows of K bf16 at pitch16 bytes): middle stage
     const uint32_t* sxi; const uint32_t* sqi;                 // row / query scales
     const float* q_resid8; const uint32_t* db_resid8_max;     // int8 residuals (eps of the certificate)
     const float* q_resid16; const uint32_t* db_resid16_max;   // bf16 residuals (threshold of the fallback)

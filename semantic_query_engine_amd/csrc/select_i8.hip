@@ -3,12 +3,15 @@
 //
 //   keys   (int8 score, row) of every row whose scaled int8 score reached the query's threshold, from the (chunk, query)
 //          lists; sorted best first in LDS (bitonic, <= 8192 keys);
-//   stage 1  the 64 best by int8 score are re-scored against the fp32 master: t1 = k-th best TRUE cosine among them, a
+//   stage 1  the 64 best by int8 score get a bf16 ESTIMATE (the row of the bf16 scan copy against the fp32 query: 2 KiB per row,
+//          error <= eps16 = scan_eps(0, largest bf16 residual of the index) ~ 0.002): t1 = (k-th best estimate) - eps16 is a
 //          lower bound of the final k-th cosine;
-//   stage 2  a row whose estimated score is below t1 - eps has a true cosine below t1: it cannot enter the top-k.  Every
-//          other collected row -- a prefix of the sorted keys -- is re-scored too (~300 rows per query on 10 M Gaussian rows
-//          against ~1,600 collected: the re-score reads 4 KiB per row, the collection 8 bytes);
-//   result  the k best of the re-scored rows by (cosine desc, row asc), exact fp32 cosines;
+//   stage 2  a row whose int8 estimate is below t1 - eps8 has a true cosine below t1: it cannot enter the top-k.  Every other
+//          collected row -- a prefix of the sorted keys, ~300 of ~2,000 on 10 M Gaussian rows -- gets its bf16 estimate too;
+//   stage 3  with t2 = (k-th best bf16 estimate of all of them) - eps16, only a row whose estimate reaches t2 - eps16 can have a
+//          true cosine >= t2: those (~15 rows) are re-scored against the fp32 master, 4 KiB per row.  (r03a re-scored all ~300
+//          in fp32: 1.2 MB per query, the HBM-bound part of this kernel; now ~0.7 MB.)
+//   result  the k best of the fp32 re-scored rows by (cosine desc, row asc), exact fp32 cosines;
 //   proof   an uncollected row has an estimated score below thr_eff (scan_i8.hip), hence a true cosine below
 //          thr_eff + eps; the query is certified when that is below the k-th cosine found, and no list or buffer overflowed.
 //          eps = scan_eps(int8 residual of the query, largest int8 residual of the index): kernels.h, the same bound the
@@ -50,15 +53,15 @@ __device__ __forceinline__ void bitonic_desc(uint64_t* v, int n) {
 
 __device__ __forceinline__ int key_score_i32(uint64_t key) { return (int)((uint32_t)(key >> 32) ^ 0x80000000u); }
 
-// true cosines of rows keys[lo .. hi) -> tk[lo .. hi) as (cosine, row) keys; one wave per row, two rows in flight
-__device__ __forceinline__ void rescore_range(const uint64_t* keys, uint64_t* tk, int lo, int hi, const float* master, const float* qrow, int K) {
+// true cosines of rows in[lo .. hi) -> out[lo .. hi) as (cosine, row) keys; one wave per row, two rows in flight
+__device__ __forceinline__ void rescore_range(const uint64_t* in, uint64_t* out, int lo, int hi, const float* master, const float* qrow, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nvec = K >> 2;
     const float4* qv = reinterpret_cast<const float4*>(qrow);
     for (int e = lo + wave * 2; e < hi; e += nw * 2) {
-        const uint32_t r0 = key_row(keys[e]);
+        const uint32_t r0 = key_row(in[e]);
         const bool two = e + 1 < hi;
-        const uint32_t r1 = two ? key_row(keys[e + 1]) : r0;
+        const uint32_t r1 = two ? key_row(in[e + 1]) : r0;
         const float4* a0 = reinterpret_cast<const float4*>(master + (size_t)r0 * K);
         const float4* a1 = reinterpret_cast<const float4*>(master + (size_t)r1 * K);
         float s0 = 0.f, s1 = 0.f;
@@ -70,8 +73,44 @@ __device__ __forceinline__ void rescore_range(const uint64_t* keys, uint64_t* tk
         s0 = wave_sum(s0) + 0.0f;
         s1 = wave_sum(s1) + 0.0f;
         if (lane == 0) {
-            tk[e] = make_key(s0, r0);
-            if (two) tk[e + 1] = make_key(s1, r1);
+            out[e] = make_key(s0, r0);
+            if (two) out[e + 1] = make_key(s1, r1);
+        }
+    }
+}
+
+// bf16 estimates of rows in[lo .. hi) -> out[lo .. hi) as (estimate, row) keys: the row of the bf16 scan copy (K bf16 at
+// `pitch` bytes) against the fp32 query, fp32 accumulation; one wave per row, two rows in flight, 16 bytes per lane and load
+__device__ __forceinline__ float dot8_bf16(const uint4 x, const float4 b0, const float4 b1, float s) {
+    s = fmaf(__uint_as_float(x.x << 16), b0.x, s); s = fmaf(__uint_as_float(x.x & 0xffff0000u), b0.y, s);
+    s = fmaf(__uint_as_float(x.y << 16), b0.z, s); s = fmaf(__uint_as_float(x.y & 0xffff0000u), b0.w, s);
+    s = fmaf(__uint_as_float(x.z << 16), b1.x, s); s = fmaf(__uint_as_float(x.z & 0xffff0000u), b1.y, s);
+    s = fmaf(__uint_as_float(x.w << 16), b1.z, s); s = fmaf(__uint_as_float(x.w & 0xffff0000u), b1.w, s);
+    return s;
+}
+__device__ __forceinline__ void estimate_range_bf16(const uint64_t* in, uint64_t* out, int lo, int hi, const char* scan16, size_t pitch,
+                                                    const float* qrow, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nvec = K >> 3;
+    const float4* qv = reinterpret_cast<const float4*>(qrow);
+    for (int e = lo + wave * 2; e < hi; e += nw * 2) {
+        const uint32_t r0 = key_row(in[e]);
+        const bool two = e + 1 < hi;
+        const uint32_t r1 = two ? key_row(in[e + 1]) : r0;
+        const uint4* a0 = reinterpret_cast<const uint4*>(scan16 + (size_t)r0 * pitch);
+        const uint4* a1 = reinterpret_cast<const uint4*>(scan16 + (size_t)r1 * pitch);
+        float s0 = 0.f, s1 = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            const uint4 x0 = a0[v], x1 = a1[v];
+            const float4 b0 = qv[2 * v], b1 = qv[2 * v + 1];
+            s0 = dot8_bf16(x0, b0, b1, s0);
+            s1 = dot8_bf16(x1, b0, b1, s1);
+        }
+        s0 = wave_sum(s0) + 0.0f;
+        s1 = wave_sum(s1) + 0.0f;
+        if (lane == 0) {
+            out[e] = make_key(s0, r0);
+            if (two) out[e + 1] = make_key(s1, r1);
         }
     }
 }
@@ -106,12 +145,14 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     while (np2 < N) np2 <<= 1;
     for (int i = N + tid; i < np2; i += blockDim.x) keys[i] = 0ull;           // key 0 sorts last (a real key is never 0)
     bitonic_desc(keys, np2);
-    // ---- stage 1
+    // ---- stage 1: bf16 estimates of the 64 best by int8 score
     const float* qrow = p.qn + (size_t)q * p.K;
+    const char* scan16 = reinterpret_cast<const char*>(p.scan16);
+    const float eps16r = scan_eps(0.f, __uint_as_float(*p.db_resid16_max), p.K);   // |bf16 row . fp32 query - true cosine|
     const int R1 = min(N, STAGE1);
-    rescore_range(keys, tk, 0, R1, p.master, qrow, p.K);
+    estimate_range_bf16(keys, tk, 0, R1, scan16, (size_t)p.pitch16, qrow, p.K);
     __syncthreads();
-    if (tid < R1) {                                                           // k-th largest of the first R1 true keys by rank counting
+    if (tid < R1) {                                                           // k-th largest of the first R1 estimates by rank counting
         const uint64_t me = tk[tid];
         int rank = 0;
         for (int j = 0; j < R1; ++j) rank += tk[j] > me ? 1 : 0;
@@ -120,9 +161,9 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     __syncthreads();
     const float eps8 = scan_eps(p.q_resid8[q], __uint_as_float(*p.db_resid8_max), p.K);
     const double unit = (double)sa.unit0 * (double)p.sqi[q];
-    int R2 = N;                                                               // fewer than k rows in stage 1: everything is re-scored
+    int R2 = N;                                                               // fewer than k rows in stage 1: everything goes on
     if (R1 >= p.k && N > R1) {
-        const float t1 = key_score(s_t1);
+        const float t1 = key_score(s_t1) - eps16r;                            // k rows have a true cosine >= t1
         // rows with score_int < thr2 have an estimated cosine below t1 - eps8, a true cosine below t1
         const double v = floor(((double)t1 - (double)eps8) / unit) - 1.0;
         const int thr2 = v < -2.0e9 ? -0x7fffffff : v > 2.0e9 ? 0x7fffffff : (int)v;
@@ -137,14 +178,37 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
         if (R2 < R1) R2 = R1;
     }
     if (R2 > RS_CAP) { R2 = RS_CAP; overflow = true; }
-    rescore_range(keys, tk, R1, R2, p.master, qrow, p.K);
+    // ---- stage 2: bf16 estimates of the rest of the prefix, all estimates in order
+    estimate_range_bf16(keys, tk, R1, R2, scan16, (size_t)p.pitch16, qrow, p.K);
     __syncthreads();
-    // ---- final order of the re-scored rows
     int rp2 = 1;
     while (rp2 < R2) rp2 <<= 1;
     for (int i = R2 + tid; i < rp2; i += blockDim.x) tk[i] = 0ull;
     bitonic_desc(tk, rp2);
-    const int m = min(R2, p.k);
+    // ---- stage 3: fp32 re-score of the rows whose estimate reaches (k-th best estimate) - 2 eps16 (a prefix of tk); `keys`
+    // is free by now and takes the (cosine, row) keys
+    if (tid == 0) s_cut = 0;
+    __syncthreads();
+    int R3 = R2;
+    if (R2 > p.k) {
+        const uint64_t cut_key = make_key(key_score(tk[p.k - 1]) - 2.0f * eps16r, 0xFFFFFFFFu);   // (lowest key of that score)
+        for (int i = tid; i < R2; i += blockDim.x) {
+            const bool below = tk[i] < cut_key;
+            const bool prev_below = i > 0 && tk[i - 1] < cut_key;
+            if (below && !prev_below) s_cut = i + 1;
+        }
+        __syncthreads();
+        R3 = s_cut > 0 ? s_cut - 1 : R2;
+        if (R3 < p.k) R3 = p.k;
+    }
+    uint64_t* fk = keys;
+    rescore_range(tk, fk, 0, R3, p.master, qrow, p.K);
+    __syncthreads();
+    int fp2 = 1;
+    while (fp2 < R3) fp2 <<= 1;
+    for (int i = R3 + tid; i < fp2; i += blockDim.x) fk[i] = 0ull;
+    bitonic_desc(fk, fp2);
+    const int m = min(R3, p.k);
     float* cos_out = p.cos_out + (size_t)q * p.k;
     int64_t* id_out = p.id_out + (size_t)q * p.k;
     // Fewer than k rows collected (the threshold sat inside a band of near-identical rows and the int8 estimates fell
@@ -158,12 +222,12 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
             cos_out[i] = cs[i];
             id_out[i] = is[i] >= 0 ? is[i] + p.id_base : -1;
         } else {
-            cos_out[i] = key_score(tk[i]);
-            id_out[i] = (int64_t)key_row(tk[i]) + p.id_base;
+            cos_out[i] = key_score(fk[i]);
+            id_out[i] = (int64_t)key_row(fk[i]) + p.id_base;
         }
     }
     if (tid == 0) {
-        const float kth = m >= p.k ? key_score(tk[p.k - 1]) : -INFINITY;
+        const float kth = m >= p.k ? key_score(fk[p.k - 1]) : -INFINITY;
         const bool certified = !overflow && m >= p.k && p.thr_eff[q] + eps8 < kth;
         float thr = INFINITY;
         if (!certified) {
@@ -176,7 +240,7 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
         p.collect_thr[q] = thr;
         if (p.stats) {
             atomicAdd(&p.stats[0], (unsigned long long)N);
-            atomicAdd(&p.stats[1], (unsigned long long)R2);
+            atomicAdd(&p.stats[1], (unsigned long long)R3);                  // rows re-scored in fp32 (R2 got a bf16 estimate)
             if (overflow) atomicAdd(&p.stats[2], 1ull);
             if (!certified) atomicAdd(&p.stats[3], 1ull);
         }
@@ -188,7 +252,7 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
 int launch_select_i8(const I8SelectArgs& a, hipStream_t stream) {
     if (a.B <= 0) return SQE_OK;
     if (a.k < 1 || a.k > STAGE1 || a.k > a.sample_m) return fail(SQE_ERR_INVALID, "int8 select: k must be in [1, min(64, sample depth)]");
-    if (a.K % 4 != 0) return fail(SQE_ERR_INVALID, "int8 select: dim must be a multiple of 4");
+    if (a.K % 8 != 0 || a.pitch16 % 16 != 0 || !a.scan16) return fail(SQE_ERR_INVALID, "int8 select: dim must be a multiple of 8, the bf16 copy 16-byte aligned rows");
     SelArgs sa;
     sa.a = a;
     const float s0 = i8_scale_unit(a.K);
