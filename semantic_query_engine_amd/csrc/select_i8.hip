@@ -2,8 +2,10 @@
 // matter, select the exact top-k and prove that no uncollected row can belong to it.  One workgroup per query.
 //
 //   keys   (int8 score, row) of every row whose scaled int8 score reached the query's threshold, from the (chunk, query)
-//          lists; sorted best first in LDS (bitonic, <= 8192 keys);
-//   stage 1  the 64 best by int8 score get a bf16 ESTIMATE (the row of the bf16 scan copy against the fp32 query: 2 KiB per row,
+//          lists, gathered into LDS (<= 8192 keys).  Nothing is sorted: the stages below are threshold filters, and a k-th largest
+//          or a final order over a few dozen to a few hundred keys is found by rank counting (r03a sorted the keys and the
+//          estimates with bitonic networks: ~110 barriers per query, half of the kernel's 140 us);
+//   stage 1  the keys above a histogram cut that leaves ~64-100 of the best int8 scores get a bf16 ESTIMATE (the row of the bf16 scan copy against the fp32 query: 2 KiB per row,
 //          error <= eps16 = scan_eps(0, largest bf16 residual of the index) ~ 0.002): t1 = (k-th best estimate) - eps16 is a
 //          lower bound of the final k-th cosine;
 //   stage 2  a row whose int8 estimate is below t1 - eps8 has a true cosine below t1: it cannot enter the top-k.  Every other
@@ -32,24 +34,6 @@ struct SelArgs {
     I8SelectArgs a;
     float unit0;                   // S0^2
 };
-
-// descending bitonic sort of n (power of two) keys in LDS, all threads of the block
-__device__ __forceinline__ void bitonic_desc(uint64_t* v, int n) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < (n >> 1); t += nt) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const uint64_t x = v[lo], y = v[hi];
-                if ((x < y) == desc) { v[lo] = y; v[hi] = x; }
-            }
-        }
-    }
-    __syncthreads();
-}
 
 __device__ __forceinline__ int key_score_i32(uint64_t key) { return (int)((uint32_t)(key >> 32) ^ 0x80000000u); }
 
@@ -90,40 +74,61 @@ __device__ __forceinline__ float dot8_bf16(const uint4 x, const float4 b0, const
 }
 __device__ __forceinline__ void estimate_range_bf16(const uint64_t* in, uint64_t* out, int lo, int hi, const char* scan16, size_t pitch,
                                                     const float* qrow, int K) {
+    constexpr int NR = 4;                      // rows in flight per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nvec = K >> 3;
     const float4* qv = reinterpret_cast<const float4*>(qrow);
-    for (int e = lo + wave * 2; e < hi; e += nw * 2) {
-        const uint32_t r0 = key_row(in[e]);
-        const bool two = e + 1 < hi;
-        const uint32_t r1 = two ? key_row(in[e + 1]) : r0;
-        const uint4* a0 = reinterpret_cast<const uint4*>(scan16 + (size_t)r0 * pitch);
-        const uint4* a1 = reinterpret_cast<const uint4*>(scan16 + (size_t)r1 * pitch);
-        float s0 = 0.f, s1 = 0.f;
-        for (int v = lane; v < nvec; v += 64) {
-            const uint4 x0 = a0[v], x1 = a1[v];
-            const float4 b0 = qv[2 * v], b1 = qv[2 * v + 1];
-            s0 = dot8_bf16(x0, b0, b1, s0);
-            s1 = dot8_bf16(x1, b0, b1, s1);
+    for (int e = lo + wave * NR; e < hi; e += nw * NR) {
+        uint32_t r[NR];
+        const uint4* a[NR];
+        float acc[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            r[i] = key_row(in[min(e + i, hi - 1)]);
+            a[i] = reinterpret_cast<const uint4*>(scan16 + (size_t)r[i] * pitch);
+            acc[i] = 0.f;
         }
-        s0 = wave_sum(s0) + 0.0f;
-        s1 = wave_sum(s1) + 0.0f;
-        if (lane == 0) {
-            out[e] = make_key(s0, r0);
-            if (two) out[e + 1] = make_key(s1, r1);
+        for (int v = lane; v < nvec; v += 64) {
+            uint4 x[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) x[i] = a[i][v];
+            const float4 b0 = qv[2 * v], b1 = qv[2 * v + 1];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) acc[i] = dot8_bf16(x[i], b0, b1, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc[i] = wave_sum(acc[i]) + 0.0f;
+        if (lane == 0) {                       // (in and out may be the same array: this wave's slots only, read above)
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+                if (e + i < hi) out[e + i] = make_key(acc[i], r[i]);
         }
     }
 }
 
+// k-th largest (1-based) of v[0 .. n) by rank counting (keys are distinct: the row is part of them) -> *out; all threads call it
+__device__ __forceinline__ void kth_largest(const uint64_t* v, int n, int k, uint64_t* out) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t me = v[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += v[j] > me ? 1 : 0;
+        if (rank == k - 1) *out = me;
+    }
+}
+
+constexpr int S1_TARGET = 64, S1_CAP = 256, NBIN = 1024;
+
 __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     const I8SelectArgs& p = sa.a;
-    __shared__ uint64_t keys[KEY_CAP];
-    __shared__ uint64_t tk[RS_CAP];
-    __shared__ int s_total, s_over, s_cut;
-    __shared__ uint64_t s_t1;
+    __shared__ uint64_t keys[KEY_CAP];     // the gathered (int8 score, row) keys; from stage 3 on the (fp32 cosine, row) keys
+    __shared__ uint64_t tk[RS_CAP];        // the histogram, then the (bf16 estimate, row) keys
+    __shared__ int s_total, s_over, s_min, s_max, s_cutbin, s_n1, s_n2, s_n3, s_wtot[16];
+    __shared__ uint64_t s_kth;
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_total = 0; s_over = 0; s_cut = 0; s_t1 = 0ull; }
+    if (tid == 0) {
+        s_total = 0; s_over = 0; s_min = 0x7fffffff; s_max = (int)0x80000000; s_cutbin = 0; s_n1 = 0; s_n2 = 0; s_n3 = 0; s_kth = 0ull;
+    }
     __syncthreads();
     // ---- gather: one wave per chunk list
     for (int c = wave; c < p.n_chunks; c += (int)(blockDim.x >> 6)) {
@@ -141,73 +146,109 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     int N = s_total;
     bool overflow = s_over != 0;
     if (N > KEY_CAP) { N = KEY_CAP; overflow = true; }
-    int np2 = 1;
-    while (np2 < N) np2 <<= 1;
-    for (int i = N + tid; i < np2; i += blockDim.x) keys[i] = 0ull;           // key 0 sorts last (a real key is never 0)
-    bitonic_desc(keys, np2);
-    // ---- stage 1: bf16 estimates of the 64 best by int8 score
+    // ---- histogram cut: the bin boundary above which ~S1_TARGET keys lie (1,024 linear bins over the scores present)
+    {
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        for (int i = tid; i < N; i += blockDim.x) {
+            const int sc = key_score_i32(keys[i]);
+            lo = min(lo, sc); hi = max(hi, sc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off, 64));
+            hi = max(hi, __shfl_xor(hi, off, 64));
+        }
+        if (lane == 0 && lo <= hi) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    }
+    int* hist = reinterpret_cast<int*>(tk);
+    for (int i = tid; i < NBIN; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const long long smin = s_min, range = (long long)s_max - smin + 1;
+    auto bin_of = [&](int sc) { return (int)((((long long)sc - smin) * NBIN) / range); };
+    for (int i = tid; i < N; i += blockDim.x) atomicAdd(&hist[bin_of(key_score_i32(keys[i]))], 1);
+    __syncthreads();
+    {
+        // suffix sums over the bins: thread t takes bin NBIN - 1 - t (a prefix scan in t); blockDim.x == NBIN
+        const int mine = hist[NBIN - 1 - tid];
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wtot[w];
+        incl += before;                                                       // keys in bins >= NBIN - 1 - tid
+        if (incl >= S1_TARGET && incl - mine < S1_TARGET) s_cutbin = NBIN - 1 - tid;
+    }
+    __syncthreads();
+    // ---- stage 1: bf16 estimates of the keys at or above the cut (any k rows give a valid lower bound: a capped subset will do)
+    const int cutbin = s_cutbin;
+    for (int i = tid; i < N; i += blockDim.x) {
+        const uint64_t key = keys[i];
+        if (bin_of(key_score_i32(key)) >= cutbin) {
+            const int at = atomicAdd(&s_n1, 1);
+            if (at < S1_CAP) {
+                tk[at] = key;                                                 // (the histogram is dead: every thread is past the barrier)
+                keys[i] = 0ull;                                               // consumed (a real key is never 0)
+            }
+        }
+    }
+    __syncthreads();
     const float* qrow = p.qn + (size_t)q * p.K;
     const char* scan16 = reinterpret_cast<const char*>(p.scan16);
     const float eps16r = scan_eps(0.f, __uint_as_float(*p.db_resid16_max), p.K);   // |bf16 row . fp32 query - true cosine|
-    const int R1 = min(N, STAGE1);
-    estimate_range_bf16(keys, tk, 0, R1, scan16, (size_t)p.pitch16, qrow, p.K);
+    const int R1 = min(s_n1, S1_CAP);
+    estimate_range_bf16(tk, tk, 0, R1, scan16, (size_t)p.pitch16, qrow, p.K);
     __syncthreads();
-    if (tid < R1) {                                                           // k-th largest of the first R1 estimates by rank counting
-        const uint64_t me = tk[tid];
-        int rank = 0;
-        for (int j = 0; j < R1; ++j) rank += tk[j] > me ? 1 : 0;
-        if (rank == p.k - 1) s_t1 = me;
-    }
+    if (R1 >= p.k) kth_largest(tk, R1, p.k, &s_kth);
     __syncthreads();
     const float eps8 = scan_eps(p.q_resid8[q], __uint_as_float(*p.db_resid8_max), p.K);
     const double unit = (double)sa.unit0 * (double)p.sqi[q];
-    int R2 = N;                                                               // fewer than k rows in stage 1: everything goes on
-    if (R1 >= p.k && N > R1) {
-        const float t1 = key_score(s_t1) - eps16r;                            // k rows have a true cosine >= t1
+    int thr2 = -0x7fffffff;                                                   // fewer than k rows in stage 1: everything goes on
+    if (R1 >= p.k) {
+        const float t1 = key_score(s_kth) - eps16r;                           // k rows have a true cosine >= t1
         // rows with score_int < thr2 have an estimated cosine below t1 - eps8, a true cosine below t1
         const double v = floor(((double)t1 - (double)eps8) / unit) - 1.0;
-        const int thr2 = v < -2.0e9 ? -0x7fffffff : v > 2.0e9 ? 0x7fffffff : (int)v;
-        // keys are sorted by score: the cut is the first position whose score is below thr2
-        for (int i = tid; i < N; i += blockDim.x) {
-            const bool below = key_score_i32(keys[i]) < thr2;
-            const bool prev_below = i > 0 && key_score_i32(keys[i - 1]) < thr2;
-            if (below && !prev_below) s_cut = i + 1;                          // + 1: 0 means "no position is below"
-        }
-        __syncthreads();
-        R2 = s_cut > 0 ? s_cut - 1 : N;
-        if (R2 < R1) R2 = R1;
+        thr2 = v < -2.0e9 ? -0x7fffffff : v > 2.0e9 ? 0x7fffffff : (int)v;
     }
+    // ---- stage 2: bf16 estimates of every other key that reaches thr2
+    if (tid == 0) s_n2 = R1;
+    __syncthreads();
+    for (int i = tid; i < N; i += blockDim.x) {
+        const uint64_t key = keys[i];
+        if (key != 0ull && key_score_i32(key) >= thr2) {
+            const int at = atomicAdd(&s_n2, 1);
+            if (at < RS_CAP) tk[at] = key;
+        }
+    }
+    __syncthreads();
+    int R2 = s_n2;
     if (R2 > RS_CAP) { R2 = RS_CAP; overflow = true; }
-    // ---- stage 2: bf16 estimates of the rest of the prefix, all estimates in order
-    estimate_range_bf16(keys, tk, R1, R2, scan16, (size_t)p.pitch16, qrow, p.K);
+    estimate_range_bf16(tk, tk, R1, R2, scan16, (size_t)p.pitch16, qrow, p.K);
     __syncthreads();
-    int rp2 = 1;
-    while (rp2 < R2) rp2 <<= 1;
-    for (int i = R2 + tid; i < rp2; i += blockDim.x) tk[i] = 0ull;
-    bitonic_desc(tk, rp2);
-    // ---- stage 3: fp32 re-score of the rows whose estimate reaches (k-th best estimate) - 2 eps16 (a prefix of tk); `keys`
-    // is free by now and takes the (cosine, row) keys
-    if (tid == 0) s_cut = 0;
-    __syncthreads();
+    // ---- stage 3: fp32 re-score of the rows whose estimate reaches (k-th best estimate) - 2 eps16; `keys` is free by now
+    uint64_t* fk = keys;
     int R3 = R2;
     if (R2 > p.k) {
-        const uint64_t cut_key = make_key(key_score(tk[p.k - 1]) - 2.0f * eps16r, 0xFFFFFFFFu);   // (lowest key of that score)
+        kth_largest(tk, R2, p.k, &s_kth);
+        __syncthreads();
+        const uint64_t cut_key = make_key(key_score(s_kth) - 2.0f * eps16r, 0xFFFFFFFFu);   // (lowest key of that score)
         for (int i = tid; i < R2; i += blockDim.x) {
-            const bool below = tk[i] < cut_key;
-            const bool prev_below = i > 0 && tk[i - 1] < cut_key;
-            if (below && !prev_below) s_cut = i + 1;
+            const uint64_t key = tk[i];
+            if (key >= cut_key) fk[atomicAdd(&s_n3, 1)] = key;
         }
         __syncthreads();
-        R3 = s_cut > 0 ? s_cut - 1 : R2;
-        if (R3 < p.k) R3 = p.k;
+        R3 = s_n3;
+    } else {
+        for (int i = tid; i < R2; i += blockDim.x) fk[i] = tk[i];
+        __syncthreads();
     }
-    uint64_t* fk = keys;
-    rescore_range(tk, fk, 0, R3, p.master, qrow, p.K);
+    rescore_range(fk, fk, 0, R3, p.master, qrow, p.K);
     __syncthreads();
-    int fp2 = 1;
-    while (fp2 < R3) fp2 <<= 1;
-    for (int i = R3 + tid; i < fp2; i += blockDim.x) fk[i] = 0ull;
-    bitonic_desc(fk, fp2);
+    // ---- result: the k best by (cosine desc, row asc), placed by rank
     const int m = min(R3, p.k);
     float* cos_out = p.cos_out + (size_t)q * p.k;
     int64_t* id_out = p.id_out + (size_t)q * p.k;
@@ -217,17 +258,26 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     const bool from_sample = m < p.k;
     const float* cs = p.sample_cos + (size_t)q * p.sample_m;
     const int64_t* is = p.sample_ids + (size_t)q * p.sample_m;
-    for (int i = tid; i < p.k; i += blockDim.x) {
-        if (from_sample) {
+    if (from_sample) {
+        for (int i = tid; i < p.k; i += blockDim.x) {
             cos_out[i] = cs[i];
             id_out[i] = is[i] >= 0 ? is[i] + p.id_base : -1;
-        } else {
-            cos_out[i] = key_score(fk[i]);
-            id_out[i] = (int64_t)key_row(fk[i]) + p.id_base;
+        }
+    } else {
+        for (int i = tid; i < R3; i += blockDim.x) {
+            const uint64_t me = fk[i];
+            int rank = 0;
+            for (int j = 0; j < R3; ++j) rank += fk[j] > me ? 1 : 0;
+            if (rank < p.k) {
+                cos_out[rank] = key_score(me);
+                id_out[rank] = (int64_t)key_row(me) + p.id_base;
+                if (rank == p.k - 1) s_kth = me;
+            }
         }
     }
+    __syncthreads();
     if (tid == 0) {
-        const float kth = m >= p.k ? key_score(fk[p.k - 1]) : -INFINITY;
+        const float kth = m >= p.k ? key_score(s_kth) : -INFINITY;
         const bool certified = !overflow && m >= p.k && p.thr_eff[q] + eps8 < kth;
         float thr = INFINITY;
         if (!certified) {
