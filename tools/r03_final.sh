@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/r03_final.sh [part]  -> gpurun_out/r03f/*: part 1 = GPU suite + default bench line + the same
 # bench under rocprofv3 + PMC passes of both first passes; part 2 = the other configs (encode / e2e with CPU baselines, IVF sweep,
-# cache, ingest, hard data), group host cost, 200 k-row HNSW baseline
+# cache, ingest, hard data), group host cost, 200 k-row HNSW baseline; part 3 = batch sweep of the flat search in both scan modes
 export TMPDIR=/tmp
 out=gpurun_out/r03f
 mkdir -p $out
@@ -18,6 +18,14 @@ if [ "$part" = "1" ]; then
   PMC_MODE=bf16 bash tools/pmc_scan.sh r03f_bf16 > $out/pmc_bf16.txt 2>&1; echo "== pmc bf16 done"; tail -25 $out/pmc_bf16.txt | cut -c1-200
   cp gpurun_out/pmc_r03f_i8_traffic.json gpurun_out/pmc_r03f_bf16_traffic.json $out/ 2>/dev/null
   rm -rf gpurun_out/pmc_r03f_i8 gpurun_out/pmc_r03f_bf16
+elif [ "$part" = "3" ]; then
+  for mode in int8 bf16; do
+    for b in 1 8 64 128 256 512 1024 2048; do
+      python bench.py --steps 10 --warmup 3 --batch $b --scan-mode $mode --no-second-leg --no-cpu-baseline --no-gemm-ref --recall-queries 16 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']
+print(json.dumps({'mode':'$mode','batch':$b,'ms_per_step':d['ms_per_step'],'qps':d['value'],'stage_ms':d['stage_ms'],'recall':d['recall_at_10'],'unc':d['uncertified_queries_last_step'],'bound':r['bound'],'frac':r['frac'],'hbm_gbps':r['hbm_gbps'],'mfma':r['mfma_tflops'],'int8':d.get('int8_last_step')}))" | tee -a $out/batch_sweep.jsonl | cut -c1-230
+    done
+  done
 else
   python bench_configs.py --mode e2e 2> $out/e2e.err | tail -1 > $out/cfg_e2e.json; echo "== e2e done"; cut -c1-400 $out/cfg_e2e.json
   python bench_configs.py --mode encode --batch 64 2> $out/encode.err | tail -1 > $out/cfg_encode.json; echo "== encode done"; cut -c1-400 $out/cfg_encode.json
