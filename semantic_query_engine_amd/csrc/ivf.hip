@@ -478,17 +478,39 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
                                                                  const int64_t* __restrict__ offsets,
                                                                  const int* __restrict__ lcount, const int* __restrict__ lq,
                                                                  int cap, int nprobe, int K, int max_len,
-                                                                 float* __restrict__ pair_scores) {
+                                                                 float* __restrict__ pair_scores,
+                                                                 const int64_t* __restrict__ probes, int n_pairs, int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sorder = reinterpret_cast<int*>(smem + LS_NST * LS_STAGE);
     float* sscale = reinterpret_cast<float*>(sorder + LS_SEG);     // [LS_SEG] row scales (sxi) of the segment's rows
     int* spair = reinterpret_cast<int*>(sscale + LS_SEG);
     float* sqscale = reinterpret_cast<float*>(spair + LS_Q);       // [LS_Q] unit^2 * sqi of the group's queries
-    const int L = blockIdx.x;
-    const int m = min(lcount[L], cap);
+    // Two grids.  List mode (n_pairs == 0): one workgroup per list, every query that probes it.  Pair mode (a handful of
+    // queries: fewer probed lists than CUs, and a CU takes in ~25 GB/s): one workgroup per (query, probe) pair and SEGMENT of its
+    // list -- `split` workgroups share a list's tiles, so one query's 32 lists are read by a few hundred CUs instead of 32.
+    const bool pair_mode = n_pairs > 0;
+    int L, m, seg = 0, pair0 = 0;
+    if (pair_mode) {
+        pair0 = (int)blockIdx.x / split;
+        seg = (int)blockIdx.x % split;
+        const int64_t l64 = probes[pair0];
+        if (l64 < 0) return;
+        L = (int)l64;
+        m = 1;
+    } else {
+        L = blockIdx.x;
+        m = min(lcount[L], cap);
+    }
     const int64_t off = offsets[L];
     const int len_all = (int)(offsets[L + 1] - off);
     if (m == 0 || len_all == 0) return;
+    int row_lo = 0, row_hi = len_all;
+    if (pair_mode && split > 1) {
+        const int nt_all = (len_all + LS_ROWS - 1) / LS_ROWS, per = (nt_all + split - 1) / split;
+        row_lo = min(len_all, seg * per * LS_ROWS);
+        row_hi = min(len_all, (seg + 1) * per * LS_ROWS);
+        if (row_lo >= row_hi) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = K / 128;                        // 128 int8 elements = 128 B per row per K step: the bf16 kernel's LDS image
@@ -496,8 +518,8 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
     const char* qb_b = reinterpret_cast<const char*>(qb);
     const int chunk_lo = lane & 7, r_in_piece = lane >> 3;
 
-    for (int seg0 = 0; seg0 < len_all; seg0 += LS_SEG) {
-        const int len = min(LS_SEG, len_all - seg0);
+    for (int seg0 = row_lo; seg0 < row_hi; seg0 += LS_SEG) {
+        const int len = min(LS_SEG, row_hi - seg0);
         __syncthreads();
         const int64_t tile0 = tile_off[L] + seg0 / LS_ROWS;                        // first tile of the segment in the copy
         for (int i = tid; i < len; i += 512) sscale[i] = (float)sxi[tile0 * LS_ROWS + i];
@@ -506,7 +528,7 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
             const int gq = min(LS_Q, m - g0);
             __syncthreads();
             if (tid < LS_Q) {
-                const int pr = lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
+                const int pr = pair_mode ? pair0 : lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
                 spair[tid] = pr;
                 sqscale[tid] = unit2 * (float)sqi[pr / nprobe];
             }
@@ -1092,9 +1114,13 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));
         const float unit = i8_scale_unit(dim);
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
-        hipLaunchKernelGGL(ivf_list_scan_i8_kernel, dim3(nlist), dim3(512), LS_LDS_I8, s, st->i8rows.as<int8_t>(), tile_stride, st->i8sxi.as<uint32_t>(),
-                           st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(),
-                           st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len, st->pair_scores.as<float>());
+        // a handful of queries: pair mode (the kernel's comment), up to 16 workgroups per probed list
+        const int n_pairs = B * nprobe <= 512 ? B * nprobe : 0;
+        const int split = n_pairs ? std::max(1, std::min(16, 512 / n_pairs)) : 1;
+        hipLaunchKernelGGL(ivf_list_scan_i8_kernel, dim3(n_pairs ? n_pairs * split : nlist), dim3(512), LS_LDS_I8, s, st->i8rows.as<int8_t>(),
+                           tile_stride, st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit,
+                           st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                           st->pair_scores.as<float>(), st->probes_ids.as<int64_t>(), n_pairs, split);
     } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel), LS_LDS));
         hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, base->scan, pitch, st->qb.as<bf16_t>(),

@@ -91,3 +91,27 @@ def test_ivf_strip_budget_sub_batches(ctx):
     # equals the expected one), ids inside a row stay distinct
     assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
     idx.close() if hasattr(idx, "close") else None
+
+
+@pytest.mark.gpu
+def test_ivf_int8_list_scan_pair_and_list_modes(ctx):
+    """dim >= 256 takes the int8 list scan over the list-ordered int8 copy.  A handful of queries run it in pair mode (one
+    workgroup per (query, probe) and list segment: ivf.hip), larger batches in list mode; both against oracle.ivf_search on
+    the exported structure, before and after rows are appended (the copy is rebuilt with the lists)."""
+    from semantic_query_engine_amd import INDEX_IVF_FLAT, VectorIndex
+    n, d, k, nlist = 60000, 256, 10, 32
+    x, cen = _clustered(n, d, 100, seed=5)
+    rng = np.random.default_rng(6)
+    q = (x[rng.integers(0, n, 96)] + 0.2 * rng.standard_normal((96, d))).astype(np.float32)
+    idx = VectorIndex(ctx, d, INDEX_IVF_FLAT, nlist)
+    idx.add(x[:50000])
+    idx.train(x[:30000], iters=6, seed=7)
+    for n_now in (50000, n):
+        if n_now > 50000:
+            idx.add(x[50000:])
+        centroids, assign = idx.ivf_export(nlist)
+        xn, qn = R.normalize_rows(x[:n_now]), R.normalize_rows(q)
+        for b, nprobe in ((1, 8), (3, 16), (16, 32), (64, 8), (96, 16)):      # 8 .. 512 pairs: pair mode; 1,536: list mode
+            cos, ids = idx.search(q[:b], k, nprobe=nprobe)
+            ref_cos, ref_ids = R.ivf_search(xn, qn[:b], centroids, assign, k, nprobe)
+            assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn[:b])
