@@ -578,7 +578,23 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
     // ---- int8 first pass (scan_mode INT8): threshold pass on a row sample (bf16 kernels, every step-th tile) -> fixed
     // per-query collect thresholds -> int8 collect scan over all rows -> staged fp32 re-score + certificate -> the bf16
     // collect pass for what is left.  Small indexes give the sample nothing to estimate from: they stay with the bf16 scan.
-    const int step8 = idx->i8_sample_step, m8 = idx->i8_sample_m;
+    int step8 = idx->i8_sample_step, m8 = idx->i8_sample_m;
+    {
+        // The bf16 kernels of the threshold pass exchange their bounds between chunks only when the sample has at least 64
+        // chunks (scan.hip: make_scan_plan); below that every workgroup keeps a quarter of its rows and the pass takes three
+        // times as long (1.25 M rows -- an eighth of the 10 M-row index, one shard of eight: 0.72 ms against 0.22 ms at
+        // 2.5 M).  Small indexes therefore sample MORE tiles (at least 128) and take a deeper place of the sample in proportion,
+        // which leaves the expected number of collected rows (~ step x m) where the options put it.
+        const int64_t tiles = (n_rows + SCAN_BM - 1) / SCAN_BM;
+        const int min_tiles = 2 * GMAX_COLS;
+        if (tiles / step8 < min_tiles && tiles / min_tiles >= 1 && tiles / min_tiles < step8) {
+            // (the place is capped at 64: the step does not go below what keeps step x m)
+            const int step_e = (int)std::max<int64_t>(std::max(1, (step8 * m8 + 63) / 64), tiles / min_tiles);
+            const int m_e = std::min(64, std::max(m8, (step8 * m8 + step_e - 1) / step_e));
+            step8 = step_e;
+            m8 = m_e;
+        }
+    }
     const bool use_i8 = idx->scan_mode == SQE_SCAN_INT8_RESCORE && certify && K >= 256 && K % 128 == 0 && k <= m8 &&
                         n_rows >= idx->i8_min_rows && n_rows >= (int64_t)step8 * SCAN_BM * 4;
     bool i8_ok = use_i8;
