@@ -464,7 +464,7 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 }
 #endif
 
-// r03 experiment, ONE barrier per half-step (period T_j; derivation: encoder.hip, gemm_pp_kernel; shipped in scan_i8.hip):
+// r03 schedule, ONE barrier per half-step (period T_j; derivation: encoder.hip, gemm_pp_kernel; scan_i8.hip has the same):
 //     G0, T_j: compute j | wait for its pieces of j + 1, read operands j + 1, issue pieces j + 3 | barrier | [tile end]
 //     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [tile end]
 // A wave keeps at most two half-steps of pieces in flight; its counted vmcnt(4) retires the older one.  Bound-table
@@ -473,10 +473,12 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 // 2 in G0, 3 in G1) does the bound work mem_phase() does, on the same schedule in x; a fetch follows the last one by at
 // least FIVE half-steps here: the fold (at + 3) of a G1 wave opens a period, a G0 wave's fetch at + 4 would leave from
 // the middle of that same period with no barrier in between.
-// Measured against the shipped schedule below (tools/r03_exp21.sh, profiles/r03_search/ab_one_barrier_bf16.log): batch 1024
-// 18.21 -> 17.86 ms, 512 equal, 256 +1-2 % -- the bf16 scan gives the cycles back as clock (the int8 scan and its 9 % do not), so
-// this form is built with -DSQE_PP_ONE_BARRIER only (tools/build_variant.sh scan_pp 1bar -DSQE_PP_ONE_BARRIER).
-#if !defined(SQE_PHASE_STAMPS) && defined(SQE_PP_ONE_BARRIER)
+// Measured against r02's schedule, a barrier after every phase (tools/r03_exp21.sh, profiles/r03_search/ab_one_barrier_bf16.log):
+// batch 1024 18.21 -> 17.86 ms, 512 equal, 256 +1-2 % (this kernel gives most of the saved cycles back as clock; the int8 scan
+// keeps its 9 %), and L2 fills 61.5 -> 30.1 GB per launch against 20.5 GB algorithmic (pmc_traffic_bf16.json): the query-block
+// workgroups of a chunk stay closer together.  Shipped; -DSQE_PP_TWO_BARRIERS and the STAMPS builds keep r02's loop.
+#if !defined(SQE_PHASE_STAMPS) && !defined(SQE_PP_TWO_BARRIERS)
+#define SQE_PP_ONE_BARRIER 1
 #define PP_WAIT_VM4() PP_WAIT(0x0F74)
 #define PP_WAIT_VM0() PP_WAIT(0x0F70)
 __device__ __forceinline__ void mem_part(PP& P, const Filter& f, AOps& a, BOps& b, int x, int ahead, bool wait_first) {
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
     __syncthreads();                       // prologue landed, state initialised
 
     {
-        // the shipped schedule, a barrier after every phase (the one-barrier experiment is above mem_part()):
+        // r02's schedule, a barrier after every phase (STAMPS builds, -DSQE_PP_TWO_BARRIERS; the shipped one is above mem_part()):
         //     G0: .. CMP_LAST(e) | MEM(e+1,0) | [SLOW(e) sync] | CMP(e+1,0) | MEM(e+1,1) ..
         //     G1: .. MEM(e,last) | CMP_LAST(e)| [SLOW(e) sync] | MEM(e+1,0) | CMP(e+1,0) ..
         if (P.J > 0) {
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 PP_STAMP(e4);
                 PP_ACC(pclk.te[0] += e1 - e0; pclk.te[1] += e2 - e1; pclk.te[2] += e3 - e2; pclk.te[3] += e4 - e3; pclk.te[4] += (cols != 0); ++pclk.te[5]);
             };
-#if !defined(SQE_PHASE_STAMPS) && defined(SQE_PP_ONE_BARRIER)
+#ifdef SQE_PP_ONE_BARRIER
             auto g1_wait = [&](int jj) {                     // after computing half-step jj: this wave's pieces of jj + 2
                 if (jj + 2 < P.J) {
                     if (jj + 3 < P.J) PP_WAIT_VM4();

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B inside one call: bf16 scan, one barrier per half-step (libsqe_knobs.so) vs a barrier after every phase (libsqe_2barpp.so; at the time of the run the one-barrier form was the default:
+# A/B inside one call: bf16 scan, one barrier per half-step (libsqe_knobs.so) vs a barrier after every phase (libsqe_2barpp.so:
 # tools/build_variant.sh scan_pp 2barpp -DSQE_PP_TWO_BARRIERS); the search tests run on the new schedule first
 set -o pipefail
 export TMPDIR=/tmp
