@@ -69,6 +69,28 @@ def test_gaussian_rows_exact_and_certified(ctx, n, d, b, k, unc_max):
     idx.close()
 
 
+def test_default_options_on_a_shard_sized_index(ctx):
+    """1.1 M x 256 rows with the DEFAULT options (int8 is the default of a flat index from 1 M rows on): 4,297 tiles, where the
+    threshold pass adapts its sample -- at least 128 tiles (every 33rd instead of every 100th) and a deeper place of it (api.hip) --
+    the size of one shard of the 10 M-row index on eight devices.  Exact answers, the int8 path answers, (almost) all certified."""
+    from semantic_query_engine_amd import VectorIndex
+    n, d, b, k = 1_100_000, 256, 512, 10
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    plant = rng.integers(0, n, b // 2)
+    q[: b // 2] = x[plant] + 0.1 * q[: b // 2]
+    idx = VectorIndex(ctx, d)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k)
+    assert np.array_equal(ids[: b // 2, 0], plant[: b // 2])
+    assert st["i8_overflows"] == 0
+    assert st["uncertified"] <= max(1, int(b * 0.05)), st
+    # ~2,000 keys per query expected (step x place ~ 2,000): the adapted sample keeps the collection where the options put it
+    assert 500 * b <= st["i8_collected"] <= 6000 * b, st
+    idx.close()
+
+
 def test_near_ties_at_the_kth_place(ctx):
     """40 planted rows per query whose true cosines differ by 1e-5 -- the int8 scores (noise ~1e-3) scramble them
     completely; the staged re-score must still return the exact order."""
