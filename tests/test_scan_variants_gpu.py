@@ -76,3 +76,28 @@ def test_timing_switches_do_not_change_answers(bits, what, knobs_env):
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "batch": 300}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, what + "\n" + out.stderr[-2000:]
     assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
+
+
+CHILD_I8 = CHILD.replace("idx = VectorIndex(ctx, d)\n", """idx = VectorIndex(ctx, d)
+from semantic_query_engine_amd import SCAN_INT8_RESCORE
+idx.set_option("scan_mode", SCAN_INT8_RESCORE); idx.set_option("i8_min_rows", 0)
+idx.set_option("i8_sample_step", 8); idx.set_option("i8_sample_m", 64)
+""").replace('print(json.dumps({"ok": True,', 'assert ctx.stats()["i8_collected"] > 0\nprint(json.dumps({"ok": True,')
+
+
+@pytest.mark.parametrize("var,val,what", [("SQE_I8_DBG", "1", "every wave issues its DMA pieces before its operand reads"),
+                                          ("SQE_I8_DBG", "2", "every wave reads its operands before it issues its pieces"),
+                                          ("SQE_I8_DBG", "4", "compute parts at normal wave priority"),
+                                          ("SQE_I8_DBG", "8", "group 0 issues its pieces before it waits (three half-steps in flight)"),
+                                          ("SQE_I8_DBG", "16", "appends of a finished tile before the barrier"),
+                                          ("SQE_I8_DBG", "0", "the shipped schedule, through the knobs build")],
+                         ids=["i8dbg1", "i8dbg2", "i8dbg4", "i8dbg8", "i8dbg16", "i8dbg0"])
+def test_int8_schedule_variants_do_not_change_answers(var, val, what, knobs_env):
+    """The variants of the int8 scan's one-barrier schedule (scan_i8.hip, SQE_I8_DBG; A/B in tools/r03_exp22.sh) move work
+    inside a period, never what is computed: each returns the oracle's answer through the int8 path (batch 300: two
+    256-query blocks per chunk)."""
+    assert "i8_sample_step" in CHILD_I8 and "i8_collected" in CHILD_I8
+    env = dict(knobs_env, **{var: val})
+    out = subprocess.run([sys.executable, "-c", CHILD_I8 % {"root": ROOT, "batch": 300}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, what + "\n" + out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["ok"] is True
