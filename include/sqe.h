@@ -121,7 +121,8 @@ int sqe_index_count(const sqe_index* idx, int64_t* out);
 int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, float* out_host);
 
 /* Options: "scan_mode" (SQE_SCAN_*; int8 tuning: "i8_min_rows", "i8_sample_step" = sample every n-th tile,
- * "i8_sample_m" = the threshold is the m-th best cosine of the sample, "i8_max_resid" = the largest int8 rounding residual
+ * "i8_sample_m" = the threshold is the m-th best score of the sample, "i8_sample_int8" = 1 (default): the sample is scanned
+ * in int8 too, 0: by the bf16 kernels with an fp32 re-score, "i8_max_resid" = the largest int8 rounding residual
  * of a stored row, default 0.02, beyond which the index answers with the bf16 scan), "rescore_k" (candidates kept by the bf16 scan,
  * 0 = automatic), "nprobe" default for IVF, "id_base" (added to every returned row id:
  * the first global row of this shard in a row-sharded index), "certify" (default 1: prove

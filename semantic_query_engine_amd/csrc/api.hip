@@ -380,6 +380,8 @@ int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
     } else if (k == "i8_sample_step") {
         if (value < 1 || value > 4096) return fail(SQE_ERR_INVALID, "i8_sample_step must be in [1, 4096]");
         idx->i8_sample_step = (int)value;
+    } else if (k == "i8_sample_int8") {
+        idx->i8_sample_int8 = value != 0 ? 1 : 0;
     } else if (k == "i8_max_resid") {
         if (!(value > 0)) return fail(SQE_ERR_INVALID, "i8_max_resid must be > 0");
         idx->i8_max_resid = value;
@@ -606,8 +608,14 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         const int q8_pitch = K + 128;
         const int n_tiles_s = (plan.n_tiles + step8 - 1) / step8;
         ScanPlan ps = make_scan_plan((int64_t)n_tiles_s * SCAN_BM, B, auto_kp(idx, m8), c->cu_count, m8);
-        SQE_TRY(idx->q8.ensure((size_t)plan.b_pad * q8_pitch));
-        SQE_TRY(idx->q8sqi.ensure((size_t)plan.b_pad * 4));
+        // the int8 threshold pass runs on query blocks of 256 whatever the batch (1 % of the tiles: padding costs nothing)
+        const int b_pad_s = (B + 255) / 256 * 256;
+        const int b_pad_q = std::max(plan.b_pad, b_pad_s);
+        const int64_t full_tiles = n_rows / SCAN_BM;
+        const int n_tiles_i8s = (int)(full_tiles / step8);          // sampled tiles t * step8, whole tiles only
+        const bool sample_i8 = idx->i8_sample_int8 != 0 && n_tiles_i8s >= 1;
+        SQE_TRY(idx->q8.ensure((size_t)b_pad_q * q8_pitch));
+        SQE_TRY(idx->q8sqi.ensure((size_t)b_pad_q * 4));
         SQE_TRY(idx->q8resid.ensure((size_t)plan.b_pad * 4));
         SQE_TRY(idx->i8thr_int.ensure((size_t)plan.b_pad * 4));
         SQE_TRY(idx->i8thr_eff.ensure((size_t)plan.b_pad * 4));
@@ -616,13 +624,31 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         SQE_TRY(idx->i8stats.ensure(64));
         {
             StageTimer t(c->prof, s, ST_PREP);
-            if (plan.b_pad > B)
-                SQE_HIP(hipMemsetAsync(idx->q8.as<char>() + (size_t)B * q8_pitch, 0, (size_t)(plan.b_pad - B) * q8_pitch, s));
+            if (b_pad_q > B)
+                SQE_HIP(hipMemsetAsync(idx->q8.as<char>() + (size_t)B * q8_pitch, 0, (size_t)(b_pad_q - B) * q8_pitch, s));
             SQE_TRY(launch_quantize_queries_i8(idx->qn.as<float>(), B, K, idx->q8.as<int8_t>(), q8_pitch, idx->q8sqi.as<uint32_t>(),
                                                idx->q8resid.as<float>(), s));
             SQE_HIP(hipMemsetAsync(idx->i8stats.p, 0, 64, s));
         }
-        {
+        if (sample_i8) {
+            // threshold pass in int8 (r03c): the collect scan's own tile loop over every step-th tile, two best scores per lane,
+            // then per query the m-th largest of them (scan_i8.hip: sample_i8_pp_kernel; select_i8.hip: i8_sample_select_kernel)
+            StageTimer t(c->prof, s, ST_SAMPLE);
+            const int qblocks_s = b_pad_s / 256;
+            const int chunks_s = std::max(1, std::min(std::min(c->cu_count / qblocks_s, 256), n_tiles_i8s));
+            SQE_TRY(idx->i8samp.ensure((size_t)chunks_s * b_pad_s * 16 * 8));
+            I8SampleArgs sp;
+            sp.db8 = idx->i8db.as<int8_t>(); sp.tile_stride = idx->i8_tile_stride; sp.sxi = idx->i8sxi.as<uint32_t>();
+            sp.q8 = idx->q8.as<int8_t>(); sp.q_pitch = q8_pitch; sp.K = K; sp.b_pad = b_pad_s; sp.n_tiles_s = n_tiles_i8s; sp.step = step8;
+            sp.n_chunks = chunks_s; sp.out = idx->i8samp.p;
+            SQE_TRY(launch_sample_i8(sp, s));
+            I8SampleSelectArgs ss;
+            ss.cand = idx->i8samp.p; ss.n_chunks = chunks_s; ss.b_pad_s = b_pad_s; ss.m = m8; ss.k = k; ss.B = B; ss.b_pad = plan.b_pad; ss.K = K;
+            ss.sqi = idx->q8sqi.as<uint32_t>(); ss.master = idx->master; ss.qn = idx->qn.as<float>();
+            ss.thr_int = idx->i8thr_int.as<int>(); ss.thr_eff = idx->i8thr_eff.as<float>();
+            ss.sample_cos = idx->i8cos_s.as<float>(); ss.sample_ids = idx->i8ids_s.as<int64_t>();
+            SQE_TRY(launch_i8_sample_select(ss, s));
+        } else {
             // threshold pass: the bf16 scan + fp32 re-score of the row sample, top-m true cosines per query
             StageTimer t(c->prof, s, ST_SAMPLE);
             ScanArgs a;

@@ -199,7 +199,7 @@ struct sqe_index {
     sqe::DevBuf i8resid_max;       // u32 float bits: max over rows of || x_hat - sxi unit x8 ||
     int64_t i8_cap_tiles = 0, i8_tile_stride = 0;
     int64_t i8_rows = 0;           // rows [0, i8_rows) of the int8 copy are current (filled lazily by the first search after an add)
-    sqe::DevBuf q8, q8sqi, q8resid, i8thr_int, i8thr_eff, i8cos_s, i8ids_s, i8stats;   // per search
+    sqe::DevBuf q8, q8sqi, q8resid, i8thr_int, i8thr_eff, i8cos_s, i8ids_s, i8stats, i8samp;   // per search
     int64_t i8_min_rows = 1000000; // below this many rows (or batches <= 128, dim < 256, k > 32) the bf16 scan answers
     int i8_sample_step = 100;      // the threshold pass scans every i8_sample_step-th tile with the bf16 kernels ...
     int i8_sample_m = 20;          // ... and the collect threshold of a query is its m-th best true cosine there (~step x m = 2,000
@@ -208,6 +208,7 @@ struct sqe_index {
                                    //   the rank-380 score -- Poisson(3.8) >= 20: 1e-8 per query; any failure costs a 3 ms bf16 pass)
     float i8_dx = 0.f;             // host copy of the int8 residual maximum (refreshed when rows were quantised)
     bool i8_dx_stale = true;
+    int i8_sample_int8 = 1;        // threshold pass: 1 = int8 sample scan + order statistic (r03c), 0 = bf16 scan + fp32 re-score of the sample
     double i8_max_resid = 0.02;    // rows that quantise worse than this (one element 40 x the others: 0.05 at dim 1024) would
                                    //   make every certificate fail: the index then answers with the bf16 scan
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT

@@ -113,6 +113,24 @@ struct I8ScanArgs {
     uint64_t* cand; int* cand_cnt;      // the bf16 scan's candidate lists: [n_chunks, b_pad, CAND_CAP], [n_chunks, b_pad]
 };
 int launch_scan_i8(const I8ScanArgs& args, hipStream_t stream);
+// Threshold pass in int8: every step-th (whole) tile against query blocks of 256; out[chunk][query][16] = the two best
+// (scaled score, row) of each of the 8 row lanes (scan_i8.hip: sample_i8_pp_kernel).  b_pad is a multiple of 256.
+struct I8SampleArgs {
+    const int8_t* db8; int64_t tile_stride; const uint32_t* sxi;
+    const int8_t* q8; int q_pitch;
+    int K, b_pad, n_tiles_s, step, n_chunks;
+    void* out;                           // int2 [n_chunks][b_pad][16]
+};
+int launch_sample_i8(const I8SampleArgs& args, hipStream_t stream);
+// Per query: the m-th largest of its n_chunks x 16 sample scores -> thr_int / thr_eff; the k best sample rows re-scored in
+// fp32 -> sample_cos / sample_ids [B][m] (k entries valid, best first): lower bounds of the k-th cosine for select_i8.
+struct I8SampleSelectArgs {
+    const void* cand; int n_chunks, b_pad_s;          // the sample kernel's output and its query padding
+    int m, k, B, b_pad, K;                            // b_pad: padding of thr_int / thr_eff (the collect scan's)
+    const uint32_t* sqi; const float* master; const float* qn;
+    int* thr_int; float* thr_eff; float* sample_cos; int64_t* sample_ids;
+};
+int launch_i8_sample_select(const I8SampleSelectArgs& args, hipStream_t stream);
 // Per query: gather the collected keys, fp32 re-score in two stages (the best 64 by int8 score give t = k-th true cosine so
 // far, then every collected row whose int8 score can still reach t), exact top-k, certificate thr_eff + eps < k-th cosine.
 // collect_thr[q] = +inf if certified, else (k-th cosine so far) - bf16 eps: the input of the bf16 collect pass (exact.hip).

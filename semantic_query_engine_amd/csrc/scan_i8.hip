@@ -88,6 +88,7 @@ struct Cur {              // a half-step: (tile entry, 64-wide slice inside it)
 struct S8 {
     const char* qbase;
     const char* scales_src;                // sxi of tile 0 of the chunk, as bytes
+    long long scales_stride = 1024;        // bytes between the scale blocks of consecutive entries (a sampled scan skips tiles)
     char* smem;
     unsigned offA0, offA1, offB0, offB1;   // per-lane source offsets of this wave's DMA pieces
     unsigned rdA, rdB;                     // per-lane LDS offsets of the operand reads inside a stage
@@ -120,7 +121,7 @@ struct S8 {
     }
     // this wave's pieces of half-step c (+ the row scales of c's tile, once per tile, from wave 0)
     __device__ __forceinline__ void issue(const Cur& c, int stage, bool all) const {
-        if (wave == 0 && c.h == 0) lds_dma16(scales_src + (long long)c.e * 1024 + lane * 16, smem + OFF_SCALES + (c.e & 1) * 1024);
+        if (wave == 0 && c.h == 0) lds_dma16(scales_src + (long long)c.e * scales_stride + lane * 16, smem + OFF_SCALES + (c.e & 1) * 1024);
         issue_a(c, stage);
         issue_b(c.h, stage, 0);
         if (all) issue_b(c.h, stage, 1);
@@ -590,6 +591,195 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Threshold pass in int8 (r03c): the same tile loop over every step-th tile of the index, no thresholds, no lists.  Each lane
+// keeps the TWO best scaled scores (and their rows) it has seen per column group -- a lane owns 32 rows of one query per tile
+// -- and writes them out at the end: [chunk][query][8 row lanes][2] (score, row).  select_i8.hip takes the m-th largest of a
+// query's n_chunks x 16 values as its collect threshold: an order statistic of the SAME quantity the collect scan compares
+// (acc x tile scale), so no bf16 scan, no fp32 re-score and no conversion stand between the sample and the threshold.  (The
+// m best of the sample are all among the candidates unless three of them fell into one lane's 32-row-per-tile stream; then the
+// threshold is the (m+1)-th best or so -- it only places the collection.)
+struct I8SampleKernelArgs {
+    const int8_t* db8; long long tile_stride; const uint32_t* sxi;
+    const int8_t* q8; int q_pitch;
+    int K, b_pad, n_tiles_s, step, n_chunks, qblocks;
+    int2* out;                // [n_chunks][b_pad][16]
+};
+
+__global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKernelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    S8 P;
+    P.lane = lane;
+    P.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = P.wave >> 2;
+    P.wm = P.wave >> 2;
+    P.wn = P.wave & 3;
+    P.order = (P.wave >> 1) & 1;
+    P.pend_h = -1;
+    P.pend_stage = 0;
+    P.defer_on = false;
+    P.smem = smem;
+    int logical = blockIdx.x;
+    const int G = gridDim.x;
+    if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
+    const int q0 = qb * BNQ;
+    int tile_begin, tile_end;
+    chunk_tile_range(p.n_tiles_s, p.n_chunks, chunk, tile_begin, tile_end);
+    P.nt = tile_end - tile_begin;
+    P.HS = p.K / 64;
+    P.J = P.nt * P.HS;
+    P.tile_bytes = p.tile_stride * p.step;
+    P.scales_stride = 1024ll * p.step;
+    const size_t ldB = (size_t)p.q_pitch;
+    {
+        const int line = P.wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((line >> 1) & 7);
+        const int row = line + 128 * (c >> 2);
+        P.offA0 = (unsigned)(row * HALF_BYTES) + (c & 3) * 16;
+        P.offB0 = (unsigned)(row * ldB) + (c & 3) * 16;
+        P.offA1 = P.offA0 + (unsigned)(64 * HALF_BYTES);
+        P.offB1 = P.offB0 + (unsigned)(64 * ldB);
+    }
+    {
+        const int r = lane & 15, cq = lane >> 4, sw = (r >> 1) & 7;
+        P.rdA = (unsigned)(r * LINE_BYTES + (((P.wm * 4 + cq) ^ sw) << 4));
+        P.rdB = (unsigned)(((P.wn & 1) * 64 + r) * LINE_BYTES + ((((P.wn >> 1) * 4 + cq) ^ sw) << 4));
+    }
+    P.qbase = reinterpret_cast<const char*>(p.q8) + (size_t)q0 * ldB;
+    P.scales_src = reinterpret_cast<const char*>(p.sxi + (size_t)tile_begin * p.step * SCAN_BM);
+    const char* tile0 = reinterpret_cast<const char*>(p.db8) + (long long)tile_begin * p.step * p.tile_stride;
+    P.rd = Cur{0, 0, tile0};
+    P.dm = Cur{0, 0, tile0};
+
+    int best[4][2], brow[4][2];                        // per column group: the two best scaled scores of this lane and their rows
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        best[c][0] = best[c][1] = (int)0x80000000;
+        brow[c][0] = brow[c][1] = -1;
+    }
+    i32x4 acc[8][4];
+    AOps a;
+    BOps b;
+    if (P.J > 0) {
+        for (int s = 0; s < 3 && s < P.J; ++s) {
+            P.issue(P.dm, s, true);
+            P.advance(P.dm);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (P.J > 0) {
+        const int HS = P.HS;
+        int j = 0;
+        auto issue_next = [&](int jj) {
+            if (jj + 3 < P.J) {
+                P.issue(P.dm, (jj + 3) & 3, true);
+                P.advance(P.dm);
+            }
+        };
+        auto wait_pieces = [&](bool younger_in_flight) {
+            if (younger_in_flight) I8_WAIT(0x0F74);
+            else I8_WAIT(0x0F70);
+        };
+        auto g0_mem = [&](int jj) {
+            if (jj + 1 < P.J) {
+                wait_pieces(jj + 2 < P.J);
+                if (P.order == 0) {
+                    issue_next(jj);
+                    read_operands(P, a, b, jj + 1);
+                } else {
+                    read_operands(P, a, b, jj + 1);
+                    issue_next(jj);
+                }
+            }
+        };
+        auto g1_mem = [&](int jj) {
+            if (P.order == 0) {
+                issue_next(jj);
+                read_operands(P, a, b, jj);
+            } else {
+                read_operands(P, a, b, jj);
+                issue_next(jj);
+            }
+        };
+        auto g1_wait = [&](int jj) {
+            if (jj + 2 < P.J) wait_pieces(jj + 3 < P.J);
+        };
+        // the finished tile into the lane's best-two lists (its scale is one per tile: quant.hip)
+        auto tile_end = [&](int e) {
+            const int s = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + OFF_SCALES + (e & 1) * 1024));
+            const int row0 = (tile_begin + e) * p.step * SCAN_BM + P.wm * 128 + (lane >> 4) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int mx = (int)0x80000000;
+#pragma unroll
+                for (int fm = 0; fm < 8; ++fm) mx = fold_i32(mx, acc[fm][c]);
+                if (__mul24(mx, s) > best[c][1]) {           // (s >= 1: the order of the raw scores is the order of the scaled ones)
+#pragma unroll
+                    for (int fm = 0; fm < 8; ++fm)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int v = __mul24(acc[fm][c][r], s);
+                            const int row = row0 + fm * 16 + r;
+                            if (v > best[c][0]) {
+                                best[c][1] = best[c][0]; brow[c][1] = brow[c][0];
+                                best[c][0] = v; brow[c][0] = row;
+                            } else if (v > best[c][1]) {
+                                best[c][1] = v; brow[c][1] = row;
+                            }
+                        }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (group == 0) {
+            read_operands(P, a, b, 0);
+            for (int e = 0; e < P.nt; ++e) {
+                cmp_phase<true>(acc, a, b);
+                g0_mem(j);
+                I8_BARRIER();
+                ++j;
+                for (int h = 1; h < HS; ++h) {
+                    cmp_phase<false>(acc, a, b);
+                    g0_mem(j);
+                    I8_BARRIER();
+                    ++j;
+                }
+                tile_end(e);
+            }
+        } else {
+            for (int e = 0; e < P.nt; ++e) {
+                g1_mem(j);
+                cmp_phase<true>(acc, a, b);
+                g1_wait(j);
+                I8_BARRIER();
+                ++j;
+                for (int h = 1; h < HS; ++h) {
+                    g1_mem(j);
+                    cmp_phase<false>(acc, a, b);
+                    g1_wait(j);
+                    I8_BARRIER();
+                    ++j;
+                }
+                tile_end(e);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- this lane's candidates: query q0 + wn * 64 + c * 16 + (lane & 15), row lane wm * 4 + (lane >> 4)
+    int2* out = p.out + ((size_t)chunk * p.b_pad + q0) * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int2* o = out + (size_t)(P.wn * 64 + c * 16 + (lane & 15)) * 16 + (P.wm * 4 + (lane >> 4)) * 2;
+        o[0] = make_int2(best[c][0], brow[c][0]);
+        o[1] = make_int2(best[c][1], brow[c][1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Small batches (<= 128 queries): the staged form of scan.hip -- one barrier per 128-element K step, 3-stage LDS ring for
 // the DB operand (two K steps of DMA in flight per CU), one 1-KiB row-scale piece per tile -- HBM-bound like its bf16
 // twin, at half the bytes per row.  Same collect semantics as the ping-pong kernel above.
@@ -786,6 +976,21 @@ int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
     auto kern = scan_i8_pp_kernel;
     SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(a.n_chunks * a.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+int launch_sample_i8(const I8SampleArgs& a, hipStream_t stream) {
+    if (a.K % 128 != 0 || a.K < 256) return fail(SQE_ERR_INVALID, "int8 sample: dim must be a multiple of 128, >= 256");
+    if (a.b_pad % BNQ != 0 || a.n_tiles_s < 1 || a.step < 1 || a.n_chunks < 1 || a.n_chunks > a.n_tiles_s)
+        return fail(SQE_ERR_INVALID, "int8 sample: bad plan");
+    I8SampleKernelArgs k;
+    k.db8 = a.db8; k.tile_stride = a.tile_stride; k.sxi = a.sxi; k.q8 = a.q8; k.q_pitch = a.q_pitch;
+    k.K = a.K; k.b_pad = a.b_pad; k.n_tiles_s = a.n_tiles_s; k.step = a.step; k.n_chunks = a.n_chunks; k.qblocks = a.b_pad / BNQ;
+    k.out = reinterpret_cast<int2*>(a.out);
+    auto kern = sample_i8_pp_kernel;
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(a.n_chunks * k.qblocks), dim3(SCAN_THREADS), LDS_BYTES, stream, k);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

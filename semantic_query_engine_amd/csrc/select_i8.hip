@@ -297,6 +297,116 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// After the int8 threshold pass (scan_i8.hip: sample_i8_pp_kernel): per query, the m-th largest of its n_chunks x 16 sample
+// scores becomes the collect threshold (same units as the collect predicate: acc x tile scale), and the k best sample rows
+// are re-scored in fp32: real rows with true cosines, the lower bounds select_i8_kernel falls back on.  One workgroup of
+// 1,024 threads per query; a 1,024-bin histogram finds the cut, rank counting orders the few values above it.
+constexpr int SS_CAP = 4096;       // sample values per query (256 chunks x 16)
+constexpr int SS_TOP = 256;        // values kept above the cut
+
+__global__ __launch_bounds__(1024) void i8_sample_select_kernel(I8SampleSelectArgs p, float unit0) {
+    __shared__ uint64_t vals[SS_CAP];
+    __shared__ uint64_t top[SS_TOP];
+    __shared__ uint64_t fk[64];
+    __shared__ int hist[1024];
+    __shared__ int s_min, s_max, s_cutbin, s_ntop, s_wtot[16];
+    __shared__ uint64_t s_mth;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = min(p.n_chunks * 16, SS_CAP);
+    if (tid == 0) { s_min = 0x7fffffff; s_max = (int)0x80000000; s_cutbin = 0; s_ntop = 0; s_mth = 0ull; }
+    hist[tid] = 0;
+    __syncthreads();
+    // ---- gather (empty slots carry row -1: key 0, which sorts last)
+    const int2* cand = reinterpret_cast<const int2*>(p.cand);
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    for (int i = tid; i < N; i += 1024) {
+        const int2 v = cand[((size_t)(i >> 4) * p.b_pad_s + q) * 16 + (i & 15)];
+        const bool ok = v.y >= 0;
+        vals[i] = ok ? (((uint64_t)((uint32_t)v.x ^ 0x80000000u) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)v.y)) : 0ull;
+        if (ok) { lo = min(lo, v.x); hi = max(hi, v.x); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
+    }
+    if (lane == 0 && lo <= hi) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    __syncthreads();
+    const long long smin = s_min, range = (long long)s_max - smin + 1;
+    auto bin_of = [&](uint64_t key) { return (int)((((long long)key_score_i32(key) - smin) * 1024) / range); };
+    for (int i = tid; i < N; i += 1024)
+        if (vals[i] != 0ull) atomicAdd(&hist[bin_of(vals[i])], 1);
+    __syncthreads();
+    const int want = min(p.m + 8, SS_TOP);             // the m-th largest lies among the values at or above the cut
+    {
+        const int mine = hist[1023 - tid];
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wtot[w];
+        incl += before;
+        if (incl >= want && incl - mine < want) s_cutbin = 1023 - tid;
+    }
+    __syncthreads();
+    const int cutbin = s_cutbin;
+    for (int i = tid; i < N; i += 1024) {
+        const uint64_t key = vals[i];
+        if (key != 0ull && bin_of(key) >= cutbin) {
+            const int at = atomicAdd(&s_ntop, 1);
+            if (at < SS_TOP) top[at] = key;
+        }
+    }
+    __syncthreads();
+    const int T = min(s_ntop, SS_TOP);
+    // ---- the m-th largest (fewer than m values: the smallest one -- a short sample collects more, never less)
+    const int mth = min(p.m, T);
+    if (T > 0) kth_largest(top, T, mth, &s_mth);
+    __syncthreads();
+    // ---- the k best sample rows, re-scored in fp32, best true cosine first
+    const int kk = min(p.k, T);
+    for (int i = tid; i < T; i += 1024) {
+        const uint64_t me = top[i];
+        int rank = 0;
+        for (int j = 0; j < T; ++j) rank += top[j] > me ? 1 : 0;
+        if (rank < kk) fk[rank] = me;
+    }
+    __syncthreads();
+    rescore_range(fk, fk, 0, kk, p.master, p.qn + (size_t)q * p.K, p.K);
+    __syncthreads();
+    float* cs = p.sample_cos + (size_t)q * p.m;
+    int64_t* is = p.sample_ids + (size_t)q * p.m;
+    for (int i = tid; i < p.m; i += 1024) {
+        if (i < kk) {
+            const uint64_t me = fk[i];
+            int rank = 0;
+            for (int j = 0; j < kk; ++j) rank += fk[j] > me ? 1 : 0;
+            cs[rank] = key_score(me);
+            is[rank] = (int64_t)key_row(me);
+        } else {
+            cs[i] = -INFINITY;
+            is[i] = -1;
+        }
+    }
+    if (tid == 0) {
+        const double unit = (double)unit0 * (double)p.sqi[q];
+        const int t = T > 0 ? key_score_i32(s_mth) : -0x7fffffff;      // no sample: collect everything (the bf16 pass answers)
+        p.thr_int[q] = t;
+        p.thr_eff[q] = (float)((double)t * unit * (1.0 + 1e-6) + 1e-7);   // rounded up (quant.hip: i8_thresholds_kernel)
+    }
+}
+
+__global__ void i8_pad_thresholds_kernel(int B, int b_pad, int* __restrict__ thr_int, float* __restrict__ thr_eff) {
+    const int q = B + blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < b_pad) { thr_int[q] = 0x7fffffff; thr_eff[q] = INFINITY; }       // padding queries collect nothing
+}
+
 }  // namespace
 
 int launch_select_i8(const I8SelectArgs& a, hipStream_t stream) {
@@ -309,6 +419,18 @@ int launch_select_i8(const I8SelectArgs& a, hipStream_t stream) {
     sa.unit0 = s0 * s0;
     // 16 waves per query: the 80 KiB of LDS admit two workgroups per CU, the re-score wants as many row fetches in flight as it can get
     hipLaunchKernelGGL(select_i8_kernel, dim3(a.B), dim3(1024), 0, stream, sa);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
+int launch_i8_sample_select(const I8SampleSelectArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return SQE_OK;
+    if (a.m < 1 || a.m > 64 || a.k < 1 || a.k > a.m || a.K % 4 != 0 || a.n_chunks < 1)
+        return fail(SQE_ERR_INVALID, "int8 sample select: 1 <= k <= m <= 64");
+    const float s0 = i8_scale_unit(a.K);
+    hipLaunchKernelGGL(i8_sample_select_kernel, dim3(a.B), dim3(1024), 0, stream, a, s0 * s0);
+    if (a.b_pad > a.B)
+        hipLaunchKernelGGL(i8_pad_thresholds_kernel, dim3((a.b_pad - a.B + 255) / 256), dim3(256), 0, stream, a.B, a.b_pad, a.thr_int, a.thr_eff);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

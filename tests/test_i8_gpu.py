@@ -91,6 +91,28 @@ def test_default_options_on_a_shard_sized_index(ctx):
     idx.close()
 
 
+@pytest.mark.parametrize("b", [300, 40])
+def test_bf16_threshold_pass_option(ctx, b):
+    """`i8_sample_int8 = 0` keeps the r03a threshold pass (bf16 scan + fp32 re-score of the row sample) in front of the int8
+    collect scan; the default is the int8 sample scan + order statistic.  Both place the collection, neither decides an answer:
+    same ids, same cosines."""
+    n, d, k = 150_000, 512, 10
+    rng = np.random.default_rng(n + b)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    out = []
+    for form in (1, 0):
+        idx = _i8_index(ctx, d, step=8, m=64)
+        idx.set_option("i8_sample_int8", form)
+        idx.add(x)
+        cos, ids, st = _check(ctx, idx, x, q, k)
+        assert st["uncertified"] <= max(1, int(b * 0.05)), st
+        out.append((cos, ids, st["i8_collected"]))
+        idx.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.allclose(out[0][0], out[1][0], atol=2e-6)
+    assert 0.3 < out[0][2] / out[1][2] < 3.0          # the two estimates of the same order statistic collect alike
+
+
 def test_near_ties_at_the_kth_place(ctx):
     """40 planted rows per query whose true cosines differ by 1e-5 -- the int8 scores (noise ~1e-3) scramble them
     completely; the staged re-score must still return the exact order."""
