@@ -77,6 +77,14 @@ struct I8KernelArgs {
 #define I8_WAIT_VM7_LGKM0() I8_WAIT(0x0077)
 #define I8_WAIT_VM0_LGKM0() I8_WAIT(0x0070)
 
+// An LDS read that overwrites the operand registers of MFMAs issued just before it is NOT held back by the hardware: with one
+// barrier per half-step both waves of a SIMD can be in their compute parts at once, a wave's last MFMAs then wait for the pipe,
+// and a ds_read issued right behind them returned its data first -- a few estimated scores per 10^10 changed from run to run
+// (tests/dbg_scan_repeat.py: the number of collected keys moved by +-4 of 2 M; with r02's barrier after every phase the barrier
+// wait sat in between).  So every wave issues its DMA pieces BEFORE its operand reads (>= ~250 cycles of issue), and where no
+// pieces are left to issue (the last three half-steps of a workgroup) it sleeps instead.
+__device__ __forceinline__ void mfma_operand_guard() { __builtin_amdgcn_s_sleep(3); }   // ~192 cycles: six 8-pass MFMAs
+
 typedef i32x4 AOps[8];    // [fm]: 128 rows x 64 k (16 int8 per lane and fragment)
 typedef i32x4 BOps[4];    // [fn]:  64 queries x 64 k
 
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
     const int group = P.wave >> 2;           // waves w and w + 4 share a SIMD
     P.wm = P.wave >> 2;
     P.wn = P.wave & 3;
-    P.order = (P.wave >> 1) & 1;
+    P.order = 0;                             // pieces, then reads, in EVERY wave: see mfma_operand_guard()
     P.pend_h = -1;
     P.pend_stage = 0;
     P.defer_on = true;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         };
 #ifndef SQE_I8_TWO_BARRIERS
         // ONE barrier per half-step (period T_j; encoder.hip's gemm_pp_kernel has the derivation):
-        //     G0, T_j: compute j | wait for its pieces of j + 1, read operands j + 1, issue pieces j + 3 | barrier | [appends]
+        //     G0, T_j: wait for its pieces of j + 1 | [appends] | compute j | read operands j + 1, issue pieces j + 3 | barrier
         //     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [appends]
         // What a period reads was waited for by its owner before the barrier that opens it; the stage its pieces go to held
         // half-step j - 1, last read before that barrier too.  A wave keeps at most two half-steps of pieces in flight, the
@@ -446,20 +454,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         // a wave's compute part runs at raised priority: when both waves of a SIMD have instructions ready, the MFMAs go first
 #define I8_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
+        // G0's wait for its pieces of jj + 1 stands at the HEAD of period T_jj (before the compute part, and before the appends
+        // of a finished tile, whose stores would otherwise count as younger entries): a read issued right behind the wait that
+        // retired its own pieces can still return the old LDS bytes (encoder.hip: g0_wait); with the compute part in between every
+        // read follows the wait that covers it by >= ~550 cycles, as in r02's schedule.
+        auto g0_wait = [&](int jj) {
+            if (jj + 1 < P.J && !(xdbg & 8)) wait_pieces(jj + 2 < P.J);
+        };
         auto g0_mem = [&](int jj) {                          // after computing half-step jj
             if (jj + 1 < P.J) {
-                if (xdbg & 8) {
+                if (xdbg & 8) {                              // (experiment: pieces first, the wait directly in front of the reads)
                     issue_next(jj);
                     if (jj + 3 < P.J) I8_WAIT(0x0F78);       // vmcnt(8)
                     else wait_pieces(jj + 2 < P.J);
                     read_operands(P, a, b, jj + 1);
                     return;
                 }
-                wait_pieces(jj + 2 < P.J);
                 if (P.order == 0) {
-                    issue_next(jj);
+                    if (jj + 3 < P.J) issue_next(jj);
+                    else mfma_operand_guard();
                     read_operands(P, a, b, jj + 1);
-                } else {
+                } else {                                     // (knobs build, SQE_I8_DBG = 2: the hazard's own experiment)
                     read_operands(P, a, b, jj + 1);
                     issue_next(jj);
                 }
@@ -467,7 +482,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         };
         auto g1_mem = [&](int jj) {                          // before computing half-step jj
             if (P.order == 0) {
-                issue_next(jj);
+                if (jj + 3 < P.J) issue_next(jj);
+                else mfma_operand_guard();
                 read_operands(P, a, b, jj);
             } else {
                 read_operands(P, a, b, jj);
@@ -479,6 +495,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         };
         if (group == 0) {
             read_operands(P, a, b, 0);
+            g0_wait(0);
             for (int e = 0; e < P.nt; ++e) {
                 I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
@@ -487,6 +504,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
+                    g0_wait(j);
                     I8_PRIO(2);
                     cmp_phase<false>(acc, a, b);
                     I8_PRIO(0);
@@ -494,6 +512,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                     I8_BARRIER();
                     ++j;
                 }
+                g0_wait(j);
                 I8_PRIO(2);
                 last_phase(e);
                 I8_PRIO(0);
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
+                g0_wait(j);                                  // (the next tile's first period: before this tile's appends)
                 if (!(xdbg & 16)) tile_end(e);
             }
         } else {
@@ -615,7 +635,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
     const int group = P.wave >> 2;
     P.wm = P.wave >> 2;
     P.wn = P.wave & 3;
-    P.order = (P.wave >> 1) & 1;
+    P.order = 0;                             // pieces, then reads, in EVERY wave: see mfma_operand_guard()
     P.pend_h = -1;
     P.pend_stage = 0;
     P.defer_on = false;
@@ -684,26 +704,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
             if (younger_in_flight) I8_WAIT(0x0F74);
             else I8_WAIT(0x0F70);
         };
-        auto g0_mem = [&](int jj) {
+        auto g0_wait = [&](int jj) {                         // at the head of a period (scan_i8_pp_kernel: g0_wait)
+            if (jj + 1 < P.J) wait_pieces(jj + 2 < P.J);
+        };
+        auto g0_mem = [&](int jj) {                          // pieces, then reads (mfma_operand_guard)
             if (jj + 1 < P.J) {
-                wait_pieces(jj + 2 < P.J);
-                if (P.order == 0) {
-                    issue_next(jj);
-                    read_operands(P, a, b, jj + 1);
-                } else {
-                    read_operands(P, a, b, jj + 1);
-                    issue_next(jj);
-                }
+                if (jj + 3 < P.J) issue_next(jj);
+                else mfma_operand_guard();
+                read_operands(P, a, b, jj + 1);
             }
         };
         auto g1_mem = [&](int jj) {
-            if (P.order == 0) {
-                issue_next(jj);
-                read_operands(P, a, b, jj);
-            } else {
-                read_operands(P, a, b, jj);
-                issue_next(jj);
-            }
+            if (jj + 3 < P.J) issue_next(jj);
+            else mfma_operand_guard();
+            read_operands(P, a, b, jj);
         };
         auto g1_wait = [&](int jj) {
             if (jj + 2 < P.J) wait_pieces(jj + 3 < P.J);
@@ -738,11 +752,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
         if (group == 0) {
             read_operands(P, a, b, 0);
             for (int e = 0; e < P.nt; ++e) {
+                g0_wait(j);
                 cmp_phase<true>(acc, a, b);
                 g0_mem(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS; ++h) {
+                    g0_wait(j);
                     cmp_phase<false>(acc, a, b);
                     g0_mem(j);
                     I8_BARRIER();

@@ -465,7 +465,7 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 #endif
 
 // r03 schedule, ONE barrier per half-step (period T_j; derivation: encoder.hip, gemm_pp_kernel; scan_i8.hip has the same):
-//     G0, T_j: compute j | wait for its pieces of j + 1, read operands j + 1, issue pieces j + 3 | barrier | [tile end]
+//     G0, T_j: wait for its pieces of j + 1 | [tile end] | compute j | read operands j + 1, issue pieces j + 3 | barrier
 //     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [tile end]
 // A wave keeps at most two half-steps of pieces in flight; its counted vmcnt(4) retires the older one.  Bound-table
 // pieces (two per wave and fetch) enter the queue in FRONT of the half-step issued with them, so the next wait retires
@@ -503,14 +503,12 @@ __device__ __forceinline__ void mem_part(PP& P, const Filter& f, AOps& a, BOps& 
             refresh_issue<true>(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
         }
     }
+    // Pieces, then reads, in every wave: an LDS read that overwrites the operand registers of MFMAs issued just before it is not
+    // held back by the hardware (scan_i8.hip: mfma_operand_guard); where no pieces are left to issue the wave sleeps instead.
     const int stage = (x + ahead) & 3;
-    if (P.order == 0) {
-        if (more) P.issue(P.dm, stage);
-        read_operands(P, a, b, x);
-    } else {
-        read_operands(P, a, b, x);
-        if (more) P.issue(P.dm, stage);
-    }
+    if (more) P.issue(P.dm, stage);
+    else __builtin_amdgcn_s_sleep(3);
+    read_operands(P, a, b, x);
     if (general) {                                       // first half-step that needs the general form again (mem_phase())
         int next;
         if (P.refresh_pending >= 0) next = max(x + 1, P.refresh_j + 3);
@@ -718,26 +716,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                     else PP_WAIT_VM0();
                 }
             };
+            // G0's wait for its pieces of half-step jj + 1 stands at the HEAD of period T_jj, in front of the compute part (and of a
+            // finished tile's filter work): a read right behind the wait that retired its own pieces can still return the old LDS
+            // bytes (encoder.hip: g0_wait); every read now follows the wait that covers it by >= ~550 cycles.
+            auto g0_wait = [&](int jj) {
+                if (jj + 1 < P.J) {
+                    if (jj + 2 < P.J) PP_WAIT_VM4();
+                    else PP_WAIT_VM0();
+                }
+            };
             if (group == 0) {
                 read_operands(P, a, b, 0);
                 P.advance(P.rd);
+                g0_wait(0);
                 for (int e = 0; e < n_entries; ++e) {
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
-                    mem_part(P, f, a, b, j + 1, 2, true);
+                    mem_part(P, f, a, b, j + 1, 2, false);
                     if (HS == 2) load_thr();
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
+                        g0_wait(j);
                         if (!P.no_mma) cmp_phase<false>(acc, a, b);
-                        mem_part(P, f, a, b, j + 1, 2, true);
+                        mem_part(P, f, a, b, j + 1, 2, false);
                         if (h == HS - 2) load_thr();
                         PP_BARRIER();
                         ++j;
                     }
+                    g0_wait(j);
                     last_phase();
-                    if (e + 1 < n_entries) mem_part(P, f, a, b, j + 1, 2, true);
+                    if (e + 1 < n_entries) mem_part(P, f, a, b, j + 1, 2, false);
                     PP_BARRIER();
                     ++j;
+                    g0_wait(j);                              // (the next entry's first period: before this tile's filter work)
                     if (e + 1 < n_entries) tile_end(e);
                 }
             } else {

@@ -113,6 +113,31 @@ def test_bf16_threshold_pass_option(ctx, b):
     assert 0.3 < out[0][2] / out[1][2] < 3.0          # the two estimates of the same order statistic collect alike
 
 
+def test_identical_calls_collect_the_same_keys(ctx):
+    """The number of keys the int8 scan collects is a function of EVERY estimated score against a fixed threshold: it must not
+    move between identical calls.  (It did, by a few keys in two million, while a wave read its operands right behind its own
+    MFMAs / right behind its own counted wait: scan_i8.hip, mfma_operand_guard and g0_wait; tests/dbg_scan_repeat.py is the
+    long form of this test.)"""
+    n, d, b, k = 600_000, 1024, 700, 10
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    idx = _i8_index(ctx, d, step=8, m=64)
+    idx.add(x)
+    seen, first = set(), None
+    for it in range(25):
+        ctx.stats_reset()
+        cos, ids = idx.search(q, k)
+        st = ctx.stats()
+        seen.add((st["i8_collected"], st["i8_rescored"], st["uncertified"]))
+        if first is None:
+            first = (cos, ids)
+        else:
+            assert np.array_equal(ids, first[1]) and np.array_equal(cos, first[0])
+    assert len(seen) == 1 and next(iter(seen))[0] > 0, seen
+    idx.close()
+
+
 def test_near_ties_at_the_kth_place(ctx):
     """40 planted rows per query whose true cosines differ by 1e-5 -- the int8 scores (noise ~1e-3) scramble them
     completely; the staged re-score must still return the exact order."""
