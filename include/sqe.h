@@ -149,6 +149,39 @@ int sqe_index_train_device(sqe_index* idx, const float* x_dev, int64_t n, int it
  * (either pointer may be NULL). */
 int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_host);
 
+/* INT8_RESCORE introspection (tests/test_i8_gpu.py: the bit-exact parity check of the int8 kernels' integer arithmetic -- the
+ * set of keys one collect launch appended against {(acc * s, row) : acc * s >= thr} recomputed from the same int8 operands in
+ * NumPy).  sqe_index_i8_last describes the LAST search this index answered with the int8 first pass (SQE_ERR_STATE if
+ * there was none); sqe_index_i8_read copies one of the device buffers that search read or wrote to the host, `bytes` bytes
+ * from byte offset `offset`.  The buffers are overwritten by the next search.  Single-device FLAT indexes only.
+ *   SQE_I8_ROWS        int8 copy of the rows, TILED: tile t (tile_rows rows) at t * tile_stride bytes; inside a tile the 64-element
+ *                      slice h of row r at h * tile_rows * 64 + r * 64
+ *   SQE_I8_ROW_SCALES  uint32 [tiles * tile_rows]: the integer scale of each row (one value per tile)
+ *   SQE_I8_QUERIES     int8 [b_pad][q_pitch]: the quantised queries, row-major (rows >= B are zero)
+ *   SQE_I8_THRESHOLDS  int32 [b_pad]: collect threshold of each query on acc * scale
+ *   SQE_I8_LIST_COUNTS int32 [n_chunks][b_pad]: keys APPENDED to each (chunk, query) list (> list_cap: the list overflowed)
+ *   SQE_I8_LISTS       uint64 [n_chunks][b_pad][list_cap]: keys, (score ^ 0x80000000) << 32 | (0xFFFFFFFF - row), unordered
+ *   SQE_I8_SAMPLE_BEST int32 [sample_chunks][sample_b_pad][8 row lanes][2][2]: threshold pass, the two best (score, row) of each
+ *                      lane stream (row lane l of a sampled tile: rows (l >> 2) * 128 + (l & 3) * 4 + 16 i + j, i < 8, j < 4) */
+typedef struct sqe_i8_launch_t {
+    int64_t rows;          /* rows scanned */
+    int64_t tile_stride;   /* bytes between tiles of the int8 copy */
+    int32_t dim, B, b_pad, k;
+    int32_t tile_rows;     /* 256 */
+    int32_t q_pitch;       /* bytes between quantised query rows */
+    int32_t query_block;   /* queries per workgroup: 256 (ping-pong kernel), 128 or 64 (staged kernels) */
+    int32_t n_chunks;      /* row chunks of the collect launch: chunk c holds tiles [c * (T / n) + min(c, T % n), ...), T tiles dealt out evenly */
+    int32_t list_cap;      /* slots per (chunk, query) list */
+    int32_t sample_int8;   /* 1: the threshold pass ran in int8 (SQE_I8_SAMPLE_BEST is valid) */
+    int32_t sample_step;   /* the threshold pass scanned tiles 0, step, 2 step, ... (whole tiles only) */
+    int32_t sample_tiles, sample_chunks, sample_b_pad, sample_m;
+    int32_t uncertified;   /* queries that went on to the bf16 collect pass (it reuses the list buffers: they are valid only when 0) */
+} sqe_i8_launch_t;
+enum { SQE_I8_ROWS = 0, SQE_I8_ROW_SCALES = 1, SQE_I8_QUERIES = 2, SQE_I8_THRESHOLDS = 3, SQE_I8_LIST_COUNTS = 4, SQE_I8_LISTS = 5,
+       SQE_I8_SAMPLE_BEST = 6 };
+int sqe_index_i8_last(sqe_index* idx, sqe_i8_launch_t* out);
+int sqe_index_i8_read(sqe_index* idx, int what, int64_t offset, void* out_host, int64_t bytes);
+
 /* Persistence.  The reference keeps its vectors in the OpenSearch index across restarts and skips the
  * rebuild when `has_any_data()` is true (main.py:300-307, :422-424); here the index lives in HBM, so it
  * is written to / read from a local file: the normalised fp32 rows (plus IVF centroids and list
@@ -241,7 +274,8 @@ typedef struct sqe_stats_t {
     int64_t scan_flops;    /* 2 * rows * dim * B of the last search */
     int64_t scan_bytes;    /* algorithmic bytes of the last search */
     int64_t uncertified;   /* queries of the last search that needed the exact fp32 rescan */
-    double sample_ms;      /* int8 mode: threshold pass (bf16 scan + re-score of the row sample) */
+    double sample_ms;      /* int8 mode: threshold pass (the int8 sample scan + order statistic, or with "i8_sample_int8" = 0 the bf16
+                            * scan + fp32 re-score of the row sample); a stage of its own, not part of scan_ms */
     int64_t i8_collected;  /* int8 mode, last search: keys the collect scan appended (all queries) */
     int64_t i8_rescored;   /*   rows re-scored in fp32 */
     int64_t i8_overflows;  /*   queries whose lists or buffers overflowed (they took the bf16 pass) */

@@ -32,6 +32,14 @@ class Stats(C.Structure):
                 ("i8_overflows", C.c_int64)]
 
 
+class I8Launch(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("tile_stride", C.c_int64), ("dim", C.c_int32), ("B", C.c_int32), ("b_pad", C.c_int32),
+                ("k", C.c_int32), ("tile_rows", C.c_int32), ("q_pitch", C.c_int32), ("query_block", C.c_int32),
+                ("n_chunks", C.c_int32), ("list_cap", C.c_int32), ("sample_int8", C.c_int32), ("sample_step", C.c_int32),
+                ("sample_tiles", C.c_int32), ("sample_chunks", C.c_int32), ("sample_b_pad", C.c_int32), ("sample_m", C.c_int32),
+                ("uncertified", C.c_int32)]
+
+
 # name -> (restype, argtypes): every symbol include/sqe.h declares
 SIGNATURES = {
     "sqe_version": (C.c_int, []),
@@ -58,6 +66,8 @@ SIGNATURES = {
     "sqe_index_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64]),
     "sqe_index_train_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64]),
     "sqe_index_ivf_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sqe_index_i8_last": (C.c_int, [C.c_void_p, C.POINTER(I8Launch)]),
+    "sqe_index_i8_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
     "sqe_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "sqe_index_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "sqe_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

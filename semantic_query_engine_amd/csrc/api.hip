@@ -420,8 +420,12 @@ static int ensure_i8_copy(sqe_index* idx, hipStream_t s) {
     const int64_t stride = (int64_t)(K / 64) * 16384 + 2048;     // + 2 KiB: chunk streams do not start at the same address modulo 256 KiB
     if (idx->i8_cap_tiles != cap_tiles || idx->i8_tile_stride != stride) {
         DevBuf nd, ns;
-        SQE_TRY(nd.ensure((size_t)cap_tiles * stride));
-        SQE_TRY(ns.ensure((size_t)cap_tiles * SCAN_BM * 4));
+        // The copy is derived data (+1 byte per element): an index that fits without it must keep answering.  SQE_ERR_OOM here
+        // sends THIS search and every later one to the bf16 scan, which needs no extra memory (index_search_impl).
+        if (nd.ensure((size_t)cap_tiles * stride) != SQE_OK || ns.ensure((size_t)cap_tiles * SCAN_BM * 4) != SQE_OK) {
+            (void)hipGetLastError();
+            return SQE_ERR_OOM;
+        }
         SQE_HIP(hipMemsetAsync(nd.p, 0, nd.bytes, s));            // rows past n read as zero vectors
         SQE_HIP(hipMemsetAsync(ns.p, 0, ns.bytes, s));
         if (idx->i8_rows > 0 && idx->i8_tile_stride == stride) {
@@ -601,8 +605,16 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
                         n_rows >= idx->i8_min_rows && n_rows >= (int64_t)step8 * SCAN_BM * 4;
     bool i8_ok = use_i8;
     if (use_i8) {
-        SQE_TRY(ensure_i8_copy(idx, s));
-        i8_ok = idx->i8_dx <= (float)idx->i8_max_resid;      // else: the bf16 scan below
+        const int rc8 = ensure_i8_copy(idx, s);
+        if (rc8 == SQE_ERR_OOM) {
+            if (!idx->i8_oom_logged) fprintf(stderr, "[sqe] no memory for the int8 copy of the rows: this index answers with the bf16 scan\n");
+            idx->i8_oom_logged = true;
+            idx->scan_mode = SQE_SCAN_BF16_RESCORE;
+            i8_ok = false;
+        } else {
+            SQE_TRY(rc8);
+            i8_ok = idx->i8_dx <= (float)idx->i8_max_resid;  // else: the bf16 scan below
+        }
     }
     if (i8_ok) {
         const int q8_pitch = K + 128;
@@ -630,12 +642,14 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
                                                idx->q8resid.as<float>(), s));
             SQE_HIP(hipMemsetAsync(idx->i8stats.p, 0, 64, s));
         }
+        int chunks_s_used = 0;
         if (sample_i8) {
             // threshold pass in int8 (r03c): the collect scan's own tile loop over every step-th tile, two best scores per lane,
             // then per query the m-th largest of them (scan_i8.hip: sample_i8_pp_kernel; select_i8.hip: i8_sample_select_kernel)
             StageTimer t(c->prof, s, ST_SAMPLE);
             const int qblocks_s = b_pad_s / 256;
             const int chunks_s = std::max(1, std::min(std::min(c->cu_count / qblocks_s, 256), n_tiles_i8s));
+            chunks_s_used = chunks_s;
             SQE_TRY(idx->i8samp.ensure((size_t)chunks_s * b_pad_s * 16 * 8));
             I8SampleArgs sp;
             sp.db8 = idx->i8db.as<int8_t>(); sp.tile_stride = idx->i8_tile_stride; sp.sxi = idx->i8sxi.as<uint32_t>();
@@ -697,6 +711,14 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             SQE_TRY(launch_select_i8(sa, s));
         }
         SQE_TRY(run_collect_fallback(idx, B, k, kp, plan.b_pad, unc_count, collect_thr, cos_out_dev, id_out_dev, pass_index, s));
+        {
+            sqe_i8_launch_t& L = idx->i8_launch;           // what sqe_index_i8_last reports (the uncertified count is read there)
+            L.rows = n_rows; L.tile_stride = idx->i8_tile_stride; L.dim = K; L.B = B; L.b_pad = plan.b_pad; L.k = k;
+            L.tile_rows = SCAN_BM; L.q_pitch = q8_pitch; L.query_block = plan.bn; L.n_chunks = plan.n_chunks; L.list_cap = CAND_CAP;
+            L.sample_int8 = sample_i8 ? 1 : 0; L.sample_step = step8; L.sample_tiles = n_tiles_i8s;
+            L.sample_chunks = chunks_s_used;
+            L.sample_b_pad = b_pad_s; L.sample_m = m8; L.uncertified = -1;
+        }
         SQE_HIP(hipMemcpyAsync(c->i8_last.p, idx->i8stats.p, 32, hipMemcpyDeviceToDevice, s));
         c->i8_valid.store(true);
         c->search_calls++;
@@ -817,6 +839,47 @@ static int search_args_ok(sqe_index* idx, const void* q, int B, int k, const voi
     if (!idx) return fail(SQE_ERR_INVALID, "null index");
     if (B < 0 || k < 1 || k > MAX_KP) return fail(SQE_ERR_INVALID, "sqe_index_search: need B >= 0 and 1 <= k <= 256");
     if (B > 0 && (!q || !cos || !ids)) return fail(SQE_ERR_INVALID, "sqe_index_search: null buffer");
+    return SQE_OK;
+}
+
+int sqe_index_i8_last(sqe_index* idx, sqe_i8_launch_t* out) {
+    if (!idx || !out) return fail(SQE_ERR_INVALID, "sqe_index_i8_last: null argument");
+    if (idx->group || idx->ivf) return fail(SQE_ERR_UNSUPPORTED, "sqe_index_i8_last: single-device FLAT indexes only");
+    OpScope op(idx->ctx, idx->ord, true);
+    if (idx->i8_launch.rows == 0) return fail(SQE_ERR_STATE, "sqe_index_i8_last: this index has not answered a search with the int8 first pass");
+    int unc = 0;
+    SQE_HIP(hipMemcpyAsync(&unc, idx->unc.p, 4, hipMemcpyDeviceToHost, op.s));
+    SQE_HIP(hipStreamSynchronize(op.s));
+    *out = idx->i8_launch;
+    out->uncertified = unc;
+    return SQE_OK;
+}
+
+int sqe_index_i8_read(sqe_index* idx, int what, int64_t offset, void* out_host, int64_t bytes) {
+    if (!idx || (!out_host && bytes > 0)) return fail(SQE_ERR_INVALID, "sqe_index_i8_read: null argument");
+    if (idx->group || idx->ivf) return fail(SQE_ERR_UNSUPPORTED, "sqe_index_i8_read: single-device FLAT indexes only");
+    OpScope op(idx->ctx, idx->ord, true);
+    const sqe_i8_launch_t& L = idx->i8_launch;
+    if (L.rows == 0) return fail(SQE_ERR_STATE, "sqe_index_i8_read: this index has not answered a search with the int8 first pass");
+    const int64_t tiles = (L.rows + L.tile_rows - 1) / L.tile_rows;
+    const void* src = nullptr;
+    int64_t size = 0;
+    switch (what) {
+        case SQE_I8_ROWS: src = idx->i8db.p; size = tiles * L.tile_stride; break;
+        case SQE_I8_ROW_SCALES: src = idx->i8sxi.p; size = tiles * L.tile_rows * 4; break;
+        case SQE_I8_QUERIES: src = idx->q8.p; size = (int64_t)L.b_pad * L.q_pitch; break;
+        case SQE_I8_THRESHOLDS: src = idx->i8thr_int.p; size = (int64_t)L.b_pad * 4; break;
+        case SQE_I8_LIST_COUNTS: src = idx->cand_cnt.p; size = (int64_t)L.n_chunks * L.b_pad * 4; break;
+        case SQE_I8_LISTS: src = idx->cand.p; size = (int64_t)L.n_chunks * L.b_pad * L.list_cap * 8; break;
+        case SQE_I8_SAMPLE_BEST:
+            if (!L.sample_int8) return fail(SQE_ERR_STATE, "sqe_index_i8_read: the threshold pass of the last search did not run in int8");
+            src = idx->i8samp.p; size = (int64_t)L.sample_chunks * L.sample_b_pad * 16 * 8; break;
+        default: return fail(SQE_ERR_INVALID, "sqe_index_i8_read: unknown buffer");
+    }
+    if (offset < 0 || bytes < 0 || offset + bytes > size) return fail(SQE_ERR_INVALID, "sqe_index_i8_read: range outside the buffer");
+    if (bytes == 0) return SQE_OK;
+    SQE_HIP(hipMemcpyAsync(out_host, static_cast<const char*>(src) + offset, (size_t)bytes, hipMemcpyDeviceToHost, op.s));
+    SQE_HIP(hipStreamSynchronize(op.s));
     return SQE_OK;
 }
 

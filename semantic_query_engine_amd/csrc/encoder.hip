@@ -431,30 +431,22 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
 // filter): 256 x 256 tiles, PERSISTENT workgroups, K in 32-wide half-steps through a 4-stage LDS ring, the two
 // waves of a SIMD taking turns at the matrix pipe: while one computes a half-step (32 MFMAs on registers) the
 // other does its memory work (4 LDS-DMA pieces, 12 ds_read_b128), one s_barrier per phase (r02's schedule: SHIPPED).
-// r03 EXPERIMENT, ablation build 512 -- measured, then taken out of the shipped kernel again: 10 % fewer cycles but 1.8 % less time,
-// and the output of 64 x 512 tokens changed in a row or two between identical calls in 7 of 30 runs even after the two hazards named
-// below were closed (the scans, which have no epilogue stores, came out clean; this kernel did not, cause not found): ONE s_barrier per half-step (period T_j)
-// instead of one per phase -- the two groups no longer wait for each other in the middle of a period, so a period
-// costs a wave's compute part plus its memory part (about 1,300 cycles) instead of twice the longer of the two
-// (about 1,700):
-//     G0 (waves 0-3), T_j: wait for its pieces of j + 1 | compute j | [epilogue] read operands j + 1, issue pieces j + 3 | barrier
-//     G1 (waves 4-7), T_j: [epilogue] read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier
-// What a period reads was waited for by its owner before the barrier that opens the period (G1's pieces of j + 1 at the
-// end of T_{j-1}, G0's pieces of j inside T_{j-1}); the stage a period's pieces go to, (j + 3) & 3, held half-step
-// j - 1, last read before that barrier too (by G0 inside T_{j-2}, by G1 at the head of T_{j-1}).  A wave keeps at
-// most two half-steps of pieces in flight: a counted vmcnt(4) retires the older one (a wave retires everything it has in flight
-// before an epilogue: no wait counts stores).  No read follows the wait that covers it directly: see g0_wait.  In wall time the change is worth less than in
-// cycles (QKV GEMM 365 k -> 328 k cycles, the encode of 64 x 512 tokens 23.9 -> 23.5 ms): the chip gives clock back.
-// A group's epilogue (VALU + stores) runs beside the OTHER group's compute part, when its operand registers are
-// dead (no spills) -- the 8-wave epilogue of gemm_persistent_kernel runs with the matrix pipe idle.  The first
-// compute part of a tile takes a zero C operand (no VALU clears).  The r02 form (two barriers per half-step, three
-// half-steps in flight) stays as ablation build 512.
+// Build 512 (tools/build_gpp_ablate.sh 512): ONE s_barrier per half-step (period T_j) instead of one per phase -- the two groups no
+// longer wait for each other in the middle of a period:
+//     G0 (waves 0-3), T_j: issue pieces j + 3 | compute j | vmcnt: own pieces of j + 2 | read operands j + 1 | barrier
+//     G1 (waves 4-7), T_j: [epilogue] issue pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | barrier
+//     (G0's last period of a tile: compute j | epilogue | issue pieces j + 3 | vmcnt | read | barrier)
+// Invariant, as in scan_i8.hip: a piece read in a period was retired by the wave that issued it before a barrier that precedes the
+// read (every wave retires its pieces of x in T_{x-2}; x is read at the end of T_{x-1} and the head of T_x).  r03's form of this
+// schedule had G0 retire its pieces of j + 1 at the head of T_j, behind the barrier -- sibling G0 waves read them unordered, and the
+// output of 64 x 512 tokens changed in a row or two between identical calls.  An epilogue always stands in FRONT of its period's
+// pieces, so the plain vmcnt(4) behind them covers its stores (operations retire in issue order).
 namespace gpp {
 // Ablation builds of the ping-pong GEMM (tools/build_gpp_ablate.sh <bits>, timing only, results wrong): 8 = no DMA pieces,
 // 16 = no operand reads, 32 = no epilogue, 64 = every tile reads the operands of tile 0 (always in L2), 128 = the pieces of a
 // half-step read whole 128-B lines of 128 rows instead of 64-B halves of 256 rows (the same bytes per tile), 256 = a 5-stage
-// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it (not together with 512); 512 = r02's schedule,
-// a barrier after every phase -- INVERTED since: 512 now selects the one-barrier experiment, the shipped kernel is r02's.  Compile-time, so
+// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it (not together with 512); 512 = the
+// one-barrier schedule described above.  Compile-time, so
 // that the shipped kernel's register allocation is the one measured (run-time switches made hipcc spill).
 #ifndef SQE_GPP_ABLATE
 #define SQE_GPP_ABLATE 0
@@ -730,105 +722,68 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 #endif
     GPP_STAMP(k0);
     if (GPP_ABLATE & 512) {
-        // EXPERIMENT (build 512): one barrier per half-step (the schedule in the comment above the kernel); not shipped, see there
+        // Build 512: one barrier per half-step (the schedule and its invariant: comment above the kernel, scan_i8.hip)
         auto issue_next = [&](int jj) {
             if (jj + 3 < J && !(GPP_ABLATE & 8)) {
                 issue(dm, (jj + 3) & 3);
                 advance(dm);
             }
         };
-        // all of this wave's pieces but its youngest half-step have landed.  No wait ever counts the epilogue's stores as entries
-        // that may stay outstanding (a vmcnt(20) = "16 stores + the youngest pieces" did: stores need not retire in order with the
-        // loads in front of them, the wait then passed with older pieces still in flight, and a few output rows of 64 x 512 tokens
-        // changed between identical calls): before an epilogue the wave retires EVERY piece it has in flight (before_epilogue), which
-        // covers what its next wait would have retired -- that one is skipped -- and the wait after that, a plain vmcnt(4), sees
-        // the stores more than a period old.
-        auto wait_pieces = [&](bool younger_in_flight) {
-            if (post_epi > 0) { --post_epi; return; }
-            if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        };
-        auto before_epilogue = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            post_epi = 1;                                    // (epilogue() sets it too: set again behind it)
-        };
-        // G0 waits for its pieces of half-step jj + 1 at the HEAD of period T_jj, before it computes: a wave that reads LDS right
-        // behind its own counted wait can still see the old bytes of the pieces that wait retired (measured: the encoder's
-        // output differed in a few rows between identical calls, cosine 0.9998-0.99998, when the wait sat directly in front of
-        // the reads; tests/dbg_enc_repeat.py) -- with the compute part and, for the other group, a barrier in between, every
-        // read comes at least ~550 cycles after the wait that covers it, as in r02's schedule.
-        auto g0_wait = [&](int jj) {
-            if (jj + 1 < J) wait_pieces(jj + 2 < J);
-        };
-        // Pieces, then reads, in EVERY wave (no stagger here): an LDS read that overwrites the operand registers of MFMAs issued
-        // just before it is not held back by the hardware, and with one barrier per half-step a wave's last MFMAs can still be
-        // waiting for the pipe (the other wave of the SIMD may be computing too) when a read issued right behind them returns
-        // (scan_i8.hip: mfma_operand_guard; the encoder's output changed in a few rows between identical calls).  The pieces are
-        // >= ~250 cycles of issue; where none are left, the wave sleeps instead.
-        auto g0_mem = [&](int jj) {                          // after computing half-step jj
-            if (jj + 1 < J) {
-                if (jj + 3 < J && !(GPP_ABLATE & 8)) issue_next(jj);
-                else __builtin_amdgcn_s_sleep(3);
-                read_operands(jj + 1);
-            }
-        };
-        auto g1_mem = [&](int jj) {                          // before computing half-step jj
-            if (jj + 3 < J && !(GPP_ABLATE & 8)) issue_next(jj);
-            else __builtin_amdgcn_s_sleep(3);
-            read_operands(jj);
-        };
-        auto g1_wait = [&](int jj) {                         // after computing half-step jj: its pieces of jj + 2
-            if (jj + 2 < J) wait_pieces(jj + 3 < J);
+        // at the end of T_jj: everything this wave has in flight but the four pieces of jj + 3 it issued LAST in this period
+        // (vector-memory operations retire in issue order: epilogue stores and residual loads are older entries)
+        auto wait_pieces = [&](int jj) {
+            if (jj + 3 < J && !(GPP_ABLATE & 8)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
         if (group == 0) {
             read_operands(0);
             for (int e = 0; e < my_tiles; ++e) {
-                g0_wait(j);
+                issue_next(j);
                 cmp_phase<true>(acc, a, b);
-                g0_mem(j);
+                wait_pieces(j);
+                if (j + 1 < J) read_operands(j + 1);
                 GPP_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
                     // (stamps of this form: [3] memory part, [4] barrier, [5] compute part, per steady period)
                     GPP_STAMP(c0);
-                    g0_wait(j);
+                    issue_next(j);
                     cmp_phase<false>(acc, a, b);
                     GPP_STAMP(c1);
-                    g0_mem(j);
+                    wait_pieces(j);
+                    if (j + 1 < J) read_operands(j + 1);
                     GPP_STAMP(c2);
                     GPP_BARRIER();
                     GPP_STAMP(t0);
                     GPP_ACC(clk[5] += c1 - c0; clk[3] += c2 - c1; clk[4] += t0 - c2; ++clk[7]; ++clk[0]);
                     ++j;
                 }
-                g0_wait(j);
+                // last period of a tile: the epilogue goes in FRONT of the period's pieces, so that the plain vmcnt(4) covers its stores
                 cmp_phase<false>(acc, a, b);
-                before_epilogue();                           // retires its pieces of j + 2 as well: the next g0_wait is skipped
                 epilogue(e);
-                post_epi = 1;
-                g0_mem(j);
+                issue_next(j);
+                wait_pieces(j);
+                if (j + 1 < J) read_operands(j + 1);
                 GPP_BARRIER();
                 ++j;
             }
         } else {
             for (int e = 0; e < my_tiles; ++e) {
-                if (e > 0) {
-                    before_epilogue();                       // retires its pieces of j + 2: this period's g1_wait is skipped
-                    epilogue(e - 1);
-                    post_epi = 1;
-                }
-                g1_mem(j);
+                if (e > 0) epilogue(e - 1);                  // beside G0's compute part; in front of this period's pieces
+                issue_next(j);
+                read_operands(j);
                 cmp_phase<true>(acc, a, b);
-                g1_wait(j);
+                wait_pieces(j);
                 GPP_BARRIER();
                 ++j;
                 for (int h = 1; h < HS; ++h) {
                     GPP_STAMP(c0);
-                    g1_mem(j);
+                    issue_next(j);
+                    read_operands(j);
                     GPP_STAMP(c1);
                     cmp_phase<false>(acc, a, b);
                     GPP_STAMP(c2);
-                    g1_wait(j);
+                    wait_pieces(j);
                     GPP_BARRIER();
                     GPP_STAMP(t0);
                     GPP_ACC(clk[3] += c1 - c0; clk[5] += c2 - c1; clk[4] += t0 - c2; ++clk[7]; ++clk[0]);

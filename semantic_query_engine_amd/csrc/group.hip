@@ -125,6 +125,9 @@ struct Group {
     Rccl rccl;
     std::vector<rccl_comm_t> comms;
     std::mutex coll_mu;                   // RCCL group calls of one process must not interleave
+    std::mutex fan_mu;                    // the workers have ONE task slot each: a fan-out holds this from its first post() to its last
+                                          // wait() (two indexes of one context searched from two threads share the workers; their
+                                          // per-index locks do not exclude each other)
 };
 
 struct GroupIndex {
@@ -604,9 +607,10 @@ int group_index_search(sqe_index* idx, const float* q, int B, int k, int nprobe,
         if (serial || g->workers.size() != (size_t)(P - 1)) {
             for (int p = 0; p < P && rc == SQE_OK; ++p) rc = shard_step(p);
         } else {
+            std::lock_guard<std::mutex> fan(g->fan_mu);
             for (int p = 1; p < P; ++p) g->workers[p - 1]->post([&shard_step, p] { return shard_step(p); });
             rc = shard_step(0);
-            for (int p = 1; p < P; ++p) {
+            for (int p = 1; p < P; ++p) {                    // every posted closure has run before this frame (shard_step, sc) goes away
                 const int r = g->workers[p - 1]->wait();
                 if (rc == SQE_OK) rc = r;
             }

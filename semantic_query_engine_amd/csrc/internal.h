@@ -208,9 +208,11 @@ struct sqe_index {
                                    //   the rank-380 score -- Poisson(3.8) >= 20: 1e-8 per query; any failure costs a 3 ms bf16 pass)
     float i8_dx = 0.f;             // host copy of the int8 residual maximum (refreshed when rows were quantised)
     bool i8_dx_stale = true;
+    bool i8_oom_logged = false;    // the int8 copy did not fit: scan_mode fell back to BF16_RESCORE (api.hip: ensure_i8_copy)
     int i8_sample_int8 = 1;        // threshold pass: 1 = int8 sample scan + order statistic (r03c), 0 = bf16 scan + fp32 re-score of the sample
     double i8_max_resid = 0.02;    // rows that quantise worse than this (one element 40 x the others: 0.05 at dim 1024) would
                                    //   make every certificate fail: the index then answers with the bf16 scan
+    sqe_i8_launch_t i8_launch{};   // the last int8 search (sqe_index_i8_last); rows == 0: none yet
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
     bool internal = false;         // sub-index of another object (IVF coarse quantiser): runs under its owner's lock and stream
     sqe::GroupIndex* group = nullptr;   // index of a multi-device context: one shard per member device (group.hip)

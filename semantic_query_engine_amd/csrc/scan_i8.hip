@@ -77,14 +77,6 @@ struct I8KernelArgs {
 #define I8_WAIT_VM7_LGKM0() I8_WAIT(0x0077)
 #define I8_WAIT_VM0_LGKM0() I8_WAIT(0x0070)
 
-// An LDS read that overwrites the operand registers of MFMAs issued just before it is NOT held back by the hardware: with one
-// barrier per half-step both waves of a SIMD can be in their compute parts at once, a wave's last MFMAs then wait for the pipe,
-// and a ds_read issued right behind them returned its data first -- a few estimated scores per 10^10 changed from run to run
-// (tests/dbg_scan_repeat.py: the number of collected keys moved by +-4 of 2 M; with r02's barrier after every phase the barrier
-// wait sat in between).  So every wave issues its DMA pieces BEFORE its operand reads (>= ~250 cycles of issue), and where no
-// pieces are left to issue (the last three half-steps of a workgroup) it sleeps instead.
-__device__ __forceinline__ void mfma_operand_guard() { __builtin_amdgcn_s_sleep(3); }   // ~192 cycles: six 8-pass MFMAs
-
 typedef i32x4 AOps[8];    // [fm]: 128 rows x 64 k (16 int8 per lane and fragment)
 typedef i32x4 BOps[4];    // [fn]:  64 queries x 64 k
 
@@ -310,7 +302,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
     const int group = P.wave >> 2;           // waves w and w + 4 share a SIMD
     P.wm = P.wave >> 2;
     P.wn = P.wave & 3;
-    P.order = 0;                             // pieces, then reads, in EVERY wave: see mfma_operand_guard()
+    P.order = 0;
     P.pend_h = -1;
     P.pend_stage = 0;
     P.defer_on = true;
@@ -424,128 +416,106 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
             }
         };
 #ifndef SQE_I8_TWO_BARRIERS
-        // ONE barrier per half-step (period T_j; encoder.hip's gemm_pp_kernel has the derivation):
-        //     G0, T_j: wait for its pieces of j + 1 | [appends] | compute j | read operands j + 1, issue pieces j + 3 | barrier
-        //     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [appends]
-        // What a period reads was waited for by its owner before the barrier that opens it; the stage its pieces go to held
-        // half-step j - 1, last read before that barrier too.  A wave keeps at most two half-steps of pieces in flight, the
-        // counted vmcnt(4) retires the older one; wave 0's scale piece and a wave's appended keys are extra YOUNGER entries of
-        // the queue at worst, which only makes a wait retire more.
+        // ONE barrier per half-step.  Period T_j is what lies between barrier B_{j-1} and barrier B_j:
+        //     G0, T_j: [appends] | issue pieces j + 3 | compute j | vmcnt: own pieces of j + 2 | read operands j + 1 | B_j
+        //     G1, T_j: [appends] | issue pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | B_j
+        // INVARIANT (every wave reads lines that all eight waves filled, and nothing but the issuing wave's vmcnt plus a barrier
+        // orders a ds_read behind another wave's LDS-DMA): a piece read in period T was retired by the wave that ISSUED it
+        // before a barrier that precedes the read.  Here every wave retires its pieces of half-step x in T_{x-2}, in front of
+        // B_{x-2}; half-step x is read at the end of T_{x-1} (G0) and at the head of T_x (G1), both behind B_{x-2}.  The stage
+        // pieces j + 3 go to held half-step j - 1, last read in T_{j-2} (G0) and at the head of T_{j-1} (G1, consumed by that
+        // period's MFMAs), both in front of B_{j-1}.  (r03 had G0 wait for its pieces of j + 1 at the HEAD of T_j, behind B_{j-1}:
+        // a sibling G0 wave's reads of j + 1 later in T_j were ordered against that wait by nothing but time.)
+        // A wave keeps at most two half-steps of pieces in flight and vmcnt(4) retires the older one: vector-memory operations
+        // retire in issue order, so wave 0's scale piece and a wave's appended keys -- extra entries of the queue, older than
+        // the four pieces of j + 3 or among them -- only make a wait retire more.
         auto issue_next = [&](int jj) {
             if (jj + 3 < P.J) {
                 P.issue(P.dm, (jj + 3) & 3, true);
                 P.advance(P.dm);
             }
         };
-        auto wait_pieces = [&](bool younger_in_flight) {
-            if (younger_in_flight) I8_WAIT(0x0F74);          // vmcnt(4)
-            else I8_WAIT(0x0F70);                            // vmcnt(0)
+        // at the end of T_jj: this wave's pieces of jj + 2 (and everything older); the pieces of jj + 3 stay in flight
+        auto wait_pieces = [&](int jj) {
+            if (jj + 3 < P.J) I8_WAIT(0x0F74);               // vmcnt(4)
+            else I8_WAIT(0x0F70);                            // vmcnt(0): nothing was issued in this period
         };
 #ifdef SQE_DEBUG_KNOBS
-        // SQE_I8_DBG (knobs build, A/B of this schedule; profiles/r03_search/ab_one_barrier_variants.log): 1 every wave
-        // pieces-then-reads (+0.1 %), 2 every wave reads-then-pieces (+1.5 %), 4 NO raised priority while computing (+1.0 %), 8 G0
-        // issues its pieces before it waits, three half-steps in flight (+-0.3 %), 16 appends before the barrier (-0.2 %)
+        // SQE_I8_DBG (knobs build, A/B of this schedule): 1 G0 issues its pieces BEHIND its compute part (one period of
+        // latency cover instead of two; the invariant holds either way), 4 NO raised priority while computing, 16 appends
+        // before the barrier
         const int xdbg = p.dbg >> 3;
-        if (xdbg & 1) P.order = 0;
-        if (xdbg & 2) P.order = 1;
 #define I8_PRIO(n) do { if (!(xdbg & 4)) __builtin_amdgcn_s_setprio(n); } while (0)
 #else
         constexpr int xdbg = 0;
         // a wave's compute part runs at raised priority: when both waves of a SIMD have instructions ready, the MFMAs go first
 #define I8_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
-        // G0's wait for its pieces of jj + 1 stands at the HEAD of period T_jj (before the compute part, and before the appends
-        // of a finished tile, whose stores would otherwise count as younger entries): a read issued right behind the wait that
-        // retired its own pieces can still return the old LDS bytes (encoder.hip: g0_wait); with the compute part in between every
-        // read follows the wait that covers it by >= ~550 cycles, as in r02's schedule.
-        auto g0_wait = [&](int jj) {
-            if (jj + 1 < P.J && !(xdbg & 8)) wait_pieces(jj + 2 < P.J);
+        // G0's half of a period around its compute part
+        auto g0_head = [&](int jj) {
+            if (!(xdbg & 1)) issue_next(jj);
         };
-        auto g0_mem = [&](int jj) {                          // after computing half-step jj
-            if (jj + 1 < P.J) {
-                if (xdbg & 8) {                              // (experiment: pieces first, the wait directly in front of the reads)
-                    issue_next(jj);
-                    if (jj + 3 < P.J) I8_WAIT(0x0F78);       // vmcnt(8)
-                    else wait_pieces(jj + 2 < P.J);
-                    read_operands(P, a, b, jj + 1);
-                    return;
-                }
-                if (P.order == 0) {
-                    if (jj + 3 < P.J) issue_next(jj);
-                    else mfma_operand_guard();
-                    read_operands(P, a, b, jj + 1);
-                } else {                                     // (knobs build, SQE_I8_DBG = 2: the hazard's own experiment)
-                    read_operands(P, a, b, jj + 1);
-                    issue_next(jj);
-                }
-            }
+        auto g0_tail = [&](int jj) {
+            if (xdbg & 1) issue_next(jj);
+            wait_pieces(jj);
+            if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
         };
-        auto g1_mem = [&](int jj) {                          // before computing half-step jj
-            if (P.order == 0) {
-                if (jj + 3 < P.J) issue_next(jj);
-                else mfma_operand_guard();
-                read_operands(P, a, b, jj);
-            } else {
-                read_operands(P, a, b, jj);
-                issue_next(jj);
-            }
-        };
-        auto g1_wait = [&](int jj) {                         // after computing half-step jj: its pieces of jj + 2
-            if (jj + 2 < P.J) wait_pieces(jj + 3 < P.J);
+        auto g1_head = [&](int jj) {
+            issue_next(jj);
+            read_operands(P, a, b, jj);
         };
         if (group == 0) {
-            read_operands(P, a, b, 0);
-            g0_wait(0);
+            read_operands(P, a, b, 0);                       // (the prologue's pieces: retired by every wave before __syncthreads)
             for (int e = 0; e < P.nt; ++e) {
+                g0_head(j);
                 I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
                 I8_PRIO(0);
-                g0_mem(j);
+                g0_tail(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
-                    g0_wait(j);
+                    g0_head(j);
                     I8_PRIO(2);
                     cmp_phase<false>(acc, a, b);
                     I8_PRIO(0);
-                    g0_mem(j);
+                    g0_tail(j);
                     I8_BARRIER();
                     ++j;
                 }
-                g0_wait(j);
+                g0_head(j);
                 I8_PRIO(2);
                 last_phase(e);
                 I8_PRIO(0);
-                g0_mem(j);
+                g0_tail(j);
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                g0_wait(j);                                  // (the next tile's first period: before this tile's appends)
-                if (!(xdbg & 16)) tile_end(e);
+                if (!(xdbg & 16)) tile_end(e);               // (the accumulators are the finished tile's until the next compute part)
             }
         } else {
             for (int e = 0; e < P.nt; ++e) {
-                g1_mem(j);
+                g1_head(j);
                 I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
                 I8_PRIO(0);
-                g1_wait(j);
+                wait_pieces(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
-                    g1_mem(j);
+                    g1_head(j);
                     I8_PRIO(2);
                     cmp_phase<false>(acc, a, b);
                     I8_PRIO(0);
-                    g1_wait(j);
+                    wait_pieces(j);
                     I8_BARRIER();
                     ++j;
                 }
-                g1_mem(j);
+                g1_head(j);
                 I8_PRIO(2);
                 last_phase(e);
                 I8_PRIO(0);
-                g1_wait(j);
+                wait_pieces(j);
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
@@ -635,7 +605,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
     const int group = P.wave >> 2;
     P.wm = P.wave >> 2;
     P.wn = P.wave & 3;
-    P.order = 0;                             // pieces, then reads, in EVERY wave: see mfma_operand_guard()
+    P.order = 0;
     P.pend_h = -1;
     P.pend_stage = 0;
     P.defer_on = false;
@@ -700,27 +670,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
                 P.advance(P.dm);
             }
         };
-        auto wait_pieces = [&](bool younger_in_flight) {
-            if (younger_in_flight) I8_WAIT(0x0F74);
+        // scan_i8_pp_kernel's schedule and invariant: every wave retires its pieces of half-step x in T_{x-2}
+        auto wait_pieces = [&](int jj) {
+            if (jj + 3 < P.J) I8_WAIT(0x0F74);
             else I8_WAIT(0x0F70);
         };
-        auto g0_wait = [&](int jj) {                         // at the head of a period (scan_i8_pp_kernel: g0_wait)
-            if (jj + 1 < P.J) wait_pieces(jj + 2 < P.J);
+        auto g0_tail = [&](int jj) {
+            wait_pieces(jj);
+            if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
         };
-        auto g0_mem = [&](int jj) {                          // pieces, then reads (mfma_operand_guard)
-            if (jj + 1 < P.J) {
-                if (jj + 3 < P.J) issue_next(jj);
-                else mfma_operand_guard();
-                read_operands(P, a, b, jj + 1);
-            }
-        };
-        auto g1_mem = [&](int jj) {
-            if (jj + 3 < P.J) issue_next(jj);
-            else mfma_operand_guard();
+        auto g1_head = [&](int jj) {
+            issue_next(jj);
             read_operands(P, a, b, jj);
-        };
-        auto g1_wait = [&](int jj) {
-            if (jj + 2 < P.J) wait_pieces(jj + 3 < P.J);
         };
         // the finished tile into the lane's best-two lists (its scale is one per tile: quant.hip)
         auto tile_end = [&](int e) {
@@ -752,15 +713,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
         if (group == 0) {
             read_operands(P, a, b, 0);
             for (int e = 0; e < P.nt; ++e) {
-                g0_wait(j);
+                issue_next(j);
                 cmp_phase<true>(acc, a, b);
-                g0_mem(j);
+                g0_tail(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS; ++h) {
-                    g0_wait(j);
+                    issue_next(j);
                     cmp_phase<false>(acc, a, b);
-                    g0_mem(j);
+                    g0_tail(j);
                     I8_BARRIER();
                     ++j;
                 }
@@ -768,15 +729,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
             }
         } else {
             for (int e = 0; e < P.nt; ++e) {
-                g1_mem(j);
+                g1_head(j);
                 cmp_phase<true>(acc, a, b);
-                g1_wait(j);
+                wait_pieces(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS; ++h) {
-                    g1_mem(j);
+                    g1_head(j);
                     cmp_phase<false>(acc, a, b);
-                    g1_wait(j);
+                    wait_pieces(j);
                     I8_BARRIER();
                     ++j;
                 }

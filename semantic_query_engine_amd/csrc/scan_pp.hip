@@ -464,35 +464,37 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 }
 #endif
 
-// r03 schedule, ONE barrier per half-step (period T_j; derivation: encoder.hip, gemm_pp_kernel; scan_i8.hip has the same):
-//     G0, T_j: wait for its pieces of j + 1 | [tile end] | compute j | read operands j + 1, issue pieces j + 3 | barrier
-//     G1, T_j: read operands j, issue pieces j + 3 | compute j | wait for its pieces of j + 2 | barrier | [tile end]
-// A wave keeps at most two half-steps of pieces in flight; its counted vmcnt(4) retires the older one.  Bound-table
-// pieces (two per wave and fetch) enter the queue in FRONT of the half-step issued with them, so the next wait retires
-// them too -- a period later; appended keys likewise.  The memory part that reads half-step x (and issues x + ahead:
-// 2 in G0, 3 in G1) does the bound work mem_phase() does, on the same schedule in x; a fetch follows the last one by at
-// least FIVE half-steps here: the fold (at + 3) of a G1 wave opens a period, a G0 wave's fetch at + 4 would leave from
-// the middle of that same period with no barrier in between.
-// Measured against r02's schedule, a barrier after every phase (tools/r03_exp21.sh, profiles/r03_search/ab_one_barrier_bf16.log):
-// batch 1024 18.21 -> 17.86 ms, 512 equal, 256 +1-2 % (this kernel gives most of the saved cycles back as clock; the int8 scan
-// keeps its 9 %), and L2 fills 61.5 -> 30.1 GB per launch against 20.5 GB algorithmic (pmc_traffic_bf16.json): the query-block
-// workgroups of a chunk stay closer together.  Shipped; -DSQE_PP_TWO_BARRIERS and the STAMPS builds keep r02's loop.
+// ONE barrier per half-step (scan_i8.hip has the same loop and the invariant's derivation).  Period T_j lies between barriers
+// B_{j-1} and B_j:
+//     G0, T_j: [tile end] | pieces j + 3 | compute j | vmcnt: own pieces of j + 2 | bound work of j + 1, read operands j + 1 | B_j
+//     G1, T_j: [tile end] | bound work of j, pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | B_j
+// INVARIANT: a piece read in period T was retired by the wave that ISSUED it before a barrier that precedes the read -- every
+// wave retires its pieces of half-step x in T_{x-2}, in front of B_{x-2}; x is read at the end of T_{x-1} (G0) and at the head
+// of T_x (G1).  (r03 had G0 retire its pieces of j + 1 at the head of T_j, behind B_{j-1}: sibling G0 waves read them later in
+// T_j ordered by nothing but time.)  A wave keeps at most two half-steps of pieces in flight; vmcnt(4) leaves the four youngest
+// entries of its queue -- the pieces of j + 3 -- and retires everything older (operations retire in issue order): the pieces
+// of j + 2, appended keys, and a bound-table fetch (two pieces per wave).  bound_work(x) is what mem_phase() does for the
+// bounds, on the same schedule in x, so every wave's private copy of that state moves alike; G0 runs it behind its compute part,
+// where no operand registers are live (the fold keeps 64 LDS reads in flight; in front of the compute part hipcc spilled).
+//   fetch issued with x = r: G0 at the end of T_{r-1}, retired by its vmcnt(4) at the end of T_r (the pieces of r + 3 are the
+//     four younger entries); G1 at the head of T_r, retired at the end of T_r.  All in front of B_r.
+//   fold, x = r + 3: a G0 wave at the end of T_{r+2}, a G1 wave at the head of T_{r+3}: behind B_r.
+//   next fetch, x >= r + 5: from T_{r+4} at the earliest, behind the barrier that follows the fold.
+// Against r02's schedule, a barrier after every phase (-DSQE_PP_TWO_BARRIERS and the STAMPS builds keep it): L2 fills 61.5 ->
+// ~30 GB per launch against 20.5 GB algorithmic (pmc_traffic_bf16.json): the query-block workgroups of a chunk stay together.
 #if !defined(SQE_PHASE_STAMPS) && !defined(SQE_PP_TWO_BARRIERS)
 #define SQE_PP_ONE_BARRIER 1
 #define PP_WAIT_VM4() PP_WAIT(0x0F74)
 #define PP_WAIT_VM0() PP_WAIT(0x0F70)
-__device__ __forceinline__ void mem_part(PP& P, const Filter& f, AOps& a, BOps& b, int x, int ahead, bool wait_first) {
-    const bool more = x + ahead < P.J && !P.no_dma;
-    const bool general = x >= P.lean_until;
-    if (general && P.refresh_pending >= 0 && x >= P.refresh_j + 3) {
+// bound work due with half-step x (= P.rd): the fold of a fetched slice, the next fetch
+__device__ __forceinline__ void bound_work(PP& P, const Filter& f, int x) {
+    if (x < P.lean_until) return;
+    const bool more = x + 2 < P.J && !P.no_dma;          // (no fetch over the last half-steps: nothing would retire it in time)
+    if (P.refresh_pending >= 0 && x >= P.refresh_j + 3) {
         if (P.wave == (P.refresh_ctr & 7)) refresh_apply(f, P.gstage, P.refresh_pending, P.gshift, P.gshift_k, P.k_rows, fresh_lane());
         P.refresh_pending = -1;
     }
-    if (wait_first) {                                    // G0: this wave's pieces of half-step x
-        if (x + 1 < P.J) PP_WAIT_VM4();
-        else PP_WAIT_VM0();
-    }
-    if (general && P.bound_on && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && x >= P.refresh_j + 5) {
+    if (P.bound_on && P.rd.e > 0 && more && !P.no_filter && P.refresh_pending < 0 && x >= P.refresh_j + 5) {
         const bool want = P.rd.e == 1 ? (P.rd.h >= P.HS / 4 && P.refresh_ctr < NSLICEP)
                                       : (P.rd.e <= P.e_fast ? (P.rd.h & P.refresh_mask) == 0
                                                             : (P.rd.h == 0 && (P.rd.e <= P.e_mid || (P.rd.e & P.late_mask) == 0)));
@@ -503,28 +505,31 @@ __device__ __forceinline__ void mem_part(PP& P, const Filter& f, AOps& a, BOps& 
             refresh_issue<true>(P.gmax_group, f.gstride, P.refresh_pending, P.gstage, P.wave, fresh_lane());
         }
     }
-    // Pieces, then reads, in every wave: an LDS read that overwrites the operand registers of MFMAs issued just before it is not
-    // held back by the hardware (scan_i8.hip: mfma_operand_guard); where no pieces are left to issue the wave sleeps instead.
-    const int stage = (x + ahead) & 3;
-    if (more) P.issue(P.dm, stage);
-    else __builtin_amdgcn_s_sleep(3);
-    read_operands(P, a, b, x);
-    if (general) {                                       // first half-step that needs the general form again (mem_phase())
-        int next;
-        if (P.refresh_pending >= 0) next = max(x + 1, P.refresh_j + 3);
-        else if (!P.bound_on || P.no_filter) next = P.J;
-        else if (P.rd.e == 0) next = P.HS + P.HS / 4;
-        else if (P.rd.e == 1) next = P.refresh_ctr < NSLICEP ? max(max(x + 1, P.refresh_j + 5), P.HS + P.HS / 4) : 2 * P.HS;
-        else if (P.rd.e <= P.e_fast) next = max(x + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask)), P.refresh_j + 5);
-        else {
-            int e2 = P.rd.e + 1;
-            if (e2 > P.e_mid) e2 = (e2 + P.late_mask) & ~P.late_mask;
-            next = e2 * P.HS;
-        }
-        P.lean_until = P.no_dma ? 0 : next;
+    // first half-step that needs this work again (mem_phase())
+    int next;
+    if (P.refresh_pending >= 0) next = max(x + 1, P.refresh_j + 3);
+    else if (!P.bound_on || P.no_filter) next = P.J;
+    else if (P.rd.e == 0) next = P.HS + P.HS / 4;
+    else if (P.rd.e == 1) next = P.refresh_ctr < NSLICEP ? max(max(x + 1, P.refresh_j + 5), P.HS + P.HS / 4) : 2 * P.HS;
+    else if (P.rd.e <= P.e_fast) next = max(x + (P.refresh_mask + 1 - (P.rd.h & P.refresh_mask)), P.refresh_j + 5);
+    else {
+        int e2 = P.rd.e + 1;
+        if (e2 > P.e_mid) e2 = (e2 + P.late_mask) & ~P.late_mask;
+        next = e2 * P.HS;
     }
+    P.lean_until = P.no_dma ? 0 : next;
+}
+// this wave's pieces of half-step y (= P.dm), if there is one
+__device__ __forceinline__ void issue_next(PP& P, int y) {
+    if (y < P.J && !P.no_dma) {
+        P.issue(P.dm, y & 3);
+        P.advance(P.dm);
+    }
+}
+// operands of half-step x (= P.rd)
+__device__ __forceinline__ void mem_read(PP& P, AOps& a, BOps& b, int x) {
+    read_operands(P, a, b, x);
     P.advance(P.rd);
-    if (more) P.advance(P.dm);
 }
 #endif
 
@@ -710,65 +715,66 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 PP_ACC(pclk.te[0] += e1 - e0; pclk.te[1] += e2 - e1; pclk.te[2] += e3 - e2; pclk.te[3] += e4 - e3; pclk.te[4] += (cols != 0); ++pclk.te[5]);
             };
 #ifdef SQE_PP_ONE_BARRIER
-            auto g1_wait = [&](int jj) {                     // after computing half-step jj: this wave's pieces of jj + 2
-                if (jj + 2 < P.J) {
-                    if (jj + 3 < P.J) PP_WAIT_VM4();
-                    else PP_WAIT_VM0();
+            // at the end of T_jj: this wave's pieces of jj + 2 and everything older; the pieces of jj + 3 stay in flight
+            auto wait_pieces = [&](int jj) {
+                if (jj + 3 < P.J && !P.no_dma) PP_WAIT_VM4();
+                else PP_WAIT_VM0();
+            };
+            auto g0_head = [&](int jj) { issue_next(P, jj + 3); };
+            auto g0_tail = [&](int jj) {
+                wait_pieces(jj);
+                if (jj + 1 < P.J) {
+                    bound_work(P, f, jj + 1);
+                    mem_read(P, a, b, jj + 1);
                 }
             };
-            // G0's wait for its pieces of half-step jj + 1 stands at the HEAD of period T_jj, in front of the compute part (and of a
-            // finished tile's filter work): a read right behind the wait that retired its own pieces can still return the old LDS
-            // bytes (encoder.hip: g0_wait); every read now follows the wait that covers it by >= ~550 cycles.
-            auto g0_wait = [&](int jj) {
-                if (jj + 1 < P.J) {
-                    if (jj + 2 < P.J) PP_WAIT_VM4();
-                    else PP_WAIT_VM0();
-                }
+            auto g1_head = [&](int jj) {
+                bound_work(P, f, jj);
+                issue_next(P, jj + 3);
+                mem_read(P, a, b, jj);
             };
             if (group == 0) {
-                read_operands(P, a, b, 0);
-                P.advance(P.rd);
-                g0_wait(0);
+                mem_read(P, a, b, 0);                        // (the prologue's pieces: retired by every wave before __syncthreads)
                 for (int e = 0; e < n_entries; ++e) {
+                    g0_head(j);
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
-                    mem_part(P, f, a, b, j + 1, 2, false);
+                    g0_tail(j);
                     if (HS == 2) load_thr();
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
-                        g0_wait(j);
+                        g0_head(j);
                         if (!P.no_mma) cmp_phase<false>(acc, a, b);
-                        mem_part(P, f, a, b, j + 1, 2, false);
+                        g0_tail(j);
                         if (h == HS - 2) load_thr();
                         PP_BARRIER();
                         ++j;
                     }
-                    g0_wait(j);
+                    g0_head(j);
                     last_phase();
-                    if (e + 1 < n_entries) mem_part(P, f, a, b, j + 1, 2, false);
+                    g0_tail(j);
                     PP_BARRIER();
                     ++j;
-                    g0_wait(j);                              // (the next entry's first period: before this tile's filter work)
-                    if (e + 1 < n_entries) tile_end(e);
+                    if (e + 1 < n_entries) tile_end(e);      // (the accumulators are the finished tile's until the next compute part)
                 }
             } else {
                 for (int e = 0; e < n_entries; ++e) {
-                    mem_part(P, f, a, b, j, 3, false);
+                    g1_head(j);
                     if (!P.no_mma) cmp_phase<true>(acc, a, b);
-                    g1_wait(j);
+                    wait_pieces(j);
                     PP_BARRIER();
                     ++j;
                     for (int h = 1; h < HS - 1; ++h) {
-                        mem_part(P, f, a, b, j, 3, false);
+                        g1_head(j);
                         if (!P.no_mma) cmp_phase<false>(acc, a, b);
-                        g1_wait(j);
+                        wait_pieces(j);
                         PP_BARRIER();
                         ++j;
                     }
-                    mem_part(P, f, a, b, j, 3, false);
+                    g1_head(j);
                     load_thr();
                     last_phase();
-                    g1_wait(j);
+                    wait_pieces(j);
                     PP_BARRIER();
                     ++j;
                     if (e + 1 < n_entries) tile_end(e);

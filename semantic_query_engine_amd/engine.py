@@ -18,6 +18,8 @@ INDEX_FLAT = 0
 INDEX_IVF_FLAT = 1
 SCAN_BF16_RESCORE = 0
 SCAN_INT8_RESCORE = 2
+# buffers of the int8 first pass (VectorIndex.i8_read; include/sqe.h: SQE_I8_*)
+I8_ROWS, I8_ROW_SCALES, I8_QUERIES, I8_THRESHOLDS, I8_LIST_COUNTS, I8_LISTS, I8_SAMPLE_BEST = range(7)
 
 
 def _f32(a: np.ndarray) -> np.ndarray:
@@ -221,6 +223,18 @@ class VectorIndex:
         asg = np.empty(len(self), np.int32)
         N.check(self.lib.sqe_index_ivf_export(self.handle, cen.ctypes.data, asg.ctypes.data))
         return cen, asg
+
+    def i8_last(self) -> dict:
+        """What the last search answered by the int8 first pass launched (sqe_index_i8_last)."""
+        L = N.I8Launch()
+        N.check(self.lib.sqe_index_i8_last(self.handle, L))
+        return {name: getattr(L, name) for name, _ in N.I8Launch._fields_}
+
+    def i8_read(self, what: int, dtype, count: int, offset_bytes: int = 0) -> np.ndarray:
+        """`count` elements of `dtype` from one of the int8 pass's device buffers (sqe_index_i8_read; what = I8_*)."""
+        out = np.empty(count, dtype)
+        N.check(self.lib.sqe_index_i8_read(self.handle, what, offset_bytes, out.ctypes.data, out.nbytes))
+        return out
 
     def search(self, q: np.ndarray, k: int, nprobe: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         """-> (cos [B,k] float32, ids [B,k] int64), best first, ties to the lowest id,

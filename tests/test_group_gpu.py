@@ -255,3 +255,38 @@ def test_objects_do_not_share_a_lock():
     assert not errors, errors
     assert len(ib) == 3000
     _check(ib, xb, xb[:16] + 0.1, 5)
+
+
+def test_two_indexes_of_one_group_searched_from_two_threads():
+    """Two indexes of ONE multi-shard context searched at once: their per-index locks do not exclude each other, and the
+    group's enqueue workers have one task slot each, so a fan-out holds the group's fan-out lock from its first post to its
+    last wait (group.hip: Group::fan_mu; without it a second post could overwrite a task -- a shard never searched, a stale
+    gather slot merged -- and leave a closure pointing into a finished call's stack frame)."""
+    import threading
+    from semantic_query_engine_amd import EXCHANGE_COPY, Context, VectorIndex
+    ctx = Context(devices=[0, 0], exchange=EXCHANGE_COPY)
+    rng = np.random.default_rng(31)
+    xa, xb = rng.standard_normal((6001, 256)).astype(np.float32), rng.standard_normal((4003, 128)).astype(np.float32)
+    ia, ib = VectorIndex(ctx, 256), VectorIndex(ctx, 128)
+    ia.add(xa)
+    ib.add(xb)
+    errors = []
+
+    def run(idx, x):
+        try:
+            for it in range(60):
+                lo = (it * 37) % (len(x) - 16)
+                cos, ids = idx.search(x[lo:lo + 16] * 1.5, 3)
+                assert np.array_equal(ids[:, 0], np.arange(lo, lo + 16)), (it, ids[:, 0])
+                assert np.all(cos[:, 0] > 0.999)
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    ts = [threading.Thread(target=run, args=a) for a in ((ia, xa), (ib, xb), (ia, xa), (ib, xb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    _check(ia, xa, xa[:8] + 0.05, 5)
+    _check(ib, xb, xb[:8] + 0.05, 5)
