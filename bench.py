@@ -47,9 +47,14 @@ PEAK_I8_TOPS = 5000.0         # dense int8 MFMA: twice the bf16 rate per clock (
 PEAK_HBM_GBPS = 8000.0
 
 
-def db_block(block: int, rows: int, device, seed: int = 1000) -> torch.Tensor:
+def db_block(block: int, rows: int, device, seed: int = 1000, centres: "torch.Tensor | None" = None) -> torch.Tensor:
+    """Block `block` of the synthetic DB: isotropic Gaussian rows, or with `centres` SURVEY 8(d)'s clustered set
+    (row = a random centre + 0.3 x Gaussian noise: what text embeddings look like)."""
     g = torch.Generator(device=device).manual_seed(seed + block)
     x = torch.randn((rows, D), generator=g, device=device, dtype=torch.float32)
+    if centres is not None:
+        lab = torch.randint(0, centres.shape[0], (rows,), generator=g, device=device)
+        x = centres[lab] + 0.3 * x
     if os.environ.get("SQE_BENCH_DATA") == "zeros":     # clock experiments only (DESIGN.md, DVFS note)
         x.zero_()
     return x
@@ -150,7 +155,9 @@ def cpu_baseline_hnsw(rows: int, b: int, k: int) -> dict:
     return {"value": round(b / dt, 1), "unit": "queries/s", "cores": int(cores), "kind": "port",
             "sample": f"HNSW m=64 ef_construction=500 ef_search=100 over {rows} x {D} rows (not scaled to the full index), "
                       f"{b} queries in {dt:.3f}s, build {build_s:.1f}s",
-            "recall_at_10": round(recall, 4), "build_s": round(build_s, 2)}
+            "recall_at_10": round(recall, 4), "build_s": round(build_s, 2), "rows": int(rows),
+            "larger_build": "200000 rows (too long a build for the default run): 2,820 queries/s, recall@10 0.708, build 266 s "
+                            "(profiles/r03_search/hnsw_200k.json); the 10 M-row index would be slower and less exact still"}
 
 
 def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
@@ -196,7 +203,7 @@ def cpu_baseline(sample_rows: int, b: int, n_total: int, k: int) -> dict:
                       f"in {dt:.2f}s, scaled linearly to {n_total} rows"}
 
 
-def exact_reference(q: torch.Tensor, n_total: int, row_lo: int, row_hi: int, k: int, device):
+def exact_reference(q: torch.Tensor, n_total: int, row_lo: int, row_hi: int, k: int, device, seed: int = 1000, centres=None):
     """Independent exact top-k (torch fp32 matmul over regenerated blocks) for the recall check."""
     qn = q / (q.norm(dim=1, keepdim=True) + 1e-9)
     best_s = torch.full((q.shape[0], 0), -float("inf"), device=device)
@@ -207,7 +214,7 @@ def exact_reference(q: torch.Tensor, n_total: int, row_lo: int, row_hi: int, k: 
         hi = min(n_total, lo + BLOCK_ROWS)
         if hi <= row_lo or lo >= row_hi:
             continue
-        x = db_block(blk, hi - lo, device)
+        x = db_block(blk, hi - lo, device, seed, centres)
         a, b_ = max(lo, row_lo) - lo, min(hi, row_hi) - lo
         x = x[a:b_]
         xn = x / (x.norm(dim=1, keepdim=True) + 1e-9)
@@ -288,9 +295,11 @@ def main():
     ap.add_argument("--i8-sample", default="", help="int8 mode: 'step,m' of the threshold pass (default: the library's 50,32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
-    ap.add_argument("--cpu-hnsw-rows", type=int, default=50_000,
-                    help="rows of the CPU HNSW baseline (0 = skip; the build is superlinear on Gaussian rows: 50 k rows take "
-                         "~1 min on 8 cores, 200 k -- profiles/r03_search/hnsw_200k.json -- several minutes)")
+    ap.add_argument("--no-clustered-leg", action="store_true",
+                    help="skip the third leg: the same search over SURVEY 8(d)'s clustered set (4096 centres, sigma 0.3), one GPU only")
+    ap.add_argument("--cpu-hnsw-rows", type=int, default=100_000,
+                    help="rows of the CPU HNSW baseline (0 = skip; the build is superlinear on Gaussian rows: 50 k rows take 20 s on "
+                         "the GPU box's 16 cores, 100 k about 75 s, 200 k -- profiles/r03_search/hnsw_200k.json -- 266 s)")
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference timing")
     ap.add_argument("--force-collective", action="store_true",
@@ -460,6 +469,32 @@ def main():
         e2, st2, cos2, ids2 = timed_leg("bf16")
         second = (e2, st2, check(cos2, ids2), bool(torch.equal(ids2, ids)), float((cos2 - cos).abs().max().item()))
 
+    # ---- third leg (one GPU): the SAME search over SURVEY 8(d)'s clustered set -- 4096 Gaussian centres, rows and queries = a centre
+    # + 0.3 x noise, ~2,400 rows per centre, all of them within the int8 bound of the query's 10th neighbour.  r03 answered this set at a
+    # third of the headline rate (every certificate failed: int8 pass + bf16 pass); the anchored threshold (select_i8.hip) certifies it.
+    clustered = None
+    if world == 1 and args.scan_mode == "int8" and not args.no_clustered_leg:
+        idx.close()
+        torch.cuda.empty_cache()
+        gc = torch.Generator(device=device).manual_seed(77)
+        centres = torch.randn((4096, D), generator=gc, device=device)
+        idx = VectorIndex(ctx, D)
+        idx.reserve(n_total)
+        for blk in range(nblocks):
+            lo, hi = blk * BLOCK_ROWS, min(n_total, (blk + 1) * BLOCK_ROWS)
+            x = db_block(blk, hi - lo, device, 5000, centres)
+            torch.cuda.synchronize()
+            idx.add_device(x.data_ptr(), hi - lo)
+            ctx.synchronize()
+            del x
+        q = centres[torch.randint(0, 4096, (b,), generator=gc, device=device)] + 0.3 * torch.randn((b, D), generator=gc, device=device)
+        searcher = ShardedSearcher(ctx, idx, id_base=0, dist=None, world=1, device=device, force_collective=False)
+        e3, st3, cos3, ids3 = timed_leg("int8")
+        ref_s, ref_i = exact_reference(q[probe], n_total, 0, n_total, k, device, 5000, centres)
+        got_i, got_s = ids3[probe], cos3[probe]
+        hits = sum(len(set(a.tolist()) & set(r.tolist())) for a, r in zip(got_i.cpu(), ref_i.cpu()))
+        clustered = (e3, st3, {"recall_at_10": round(hits / (nq * k), 4), "max_abs_dcos": float((got_s - ref_s).abs().max().item())})
+
     if rank == 0:
         head = describe(args.scan_mode, elapsed, st)
         roof = head["roofline"]
@@ -497,6 +532,13 @@ def main():
             out["bf16_scan"] = {"note": f"second leg, same index, queries, K = {args.steps} steps after W = {args.warmup} warm-ups: the bf16 "
                                         "first pass (scan_mode = SQE_SCAN_BF16_RESCORE); not part of `value`",
                                 **leg, **chk2, "ids_equal_to_headline_leg": same_ids, "max_abs_dcos_vs_headline_leg": dcos}
+        if clustered is not None:
+            e3, st3, chk3 = clustered
+            leg = describe("int8", e3, st3)
+            leg.pop("used_i8")
+            out["clustered"] = {"note": f"third leg, same size, batch and options over SURVEY 8(d)'s clustered set (4096 Gaussian centres, rows and queries = "
+                                        f"centre + 0.3 x noise), K = {args.steps} steps after W = {args.warmup} warm-ups; not part of `value`",
+                                **leg, **chk3}
         if args.force_collective:
             out["config"]["rehearsal"] = "one-rank nccl group, all-gather + merge path forced"
         if not args.no_cpu_baseline and world == 1:

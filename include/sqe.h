@@ -121,7 +121,10 @@ int sqe_index_count(const sqe_index* idx, int64_t* out);
 int sqe_index_get_rows(sqe_index* idx, const int64_t* rows_host, int64_t n, float* out_host);
 
 /* Options: "scan_mode" (SQE_SCAN_*; int8 tuning: "i8_min_rows", "i8_sample_step" = sample every n-th tile,
- * "i8_sample_m" = the threshold is the m-th best score of the sample, "i8_sample_int8" = 1 (default): the sample is scanned
+ * "i8_sample_m" = the threshold is the m-th best score of the sample, "i8_anchor_margin" (default 0.25): the threshold never
+ * lies above (best true cosine of the sample) - eps * (1 + margin), which makes the int8 certificate hold by construction on rows
+ * that crowd together, "i8_key_budget" (default 6144; 0 = no limit): where the sample predicts that the anchored threshold would collect more
+ * keys than this, the m-th sample score alone stands, "i8_sample_int8" = 1 (default): the sample is scanned
  * in int8 too, 0: by the bf16 kernels with an fp32 re-score, "i8_max_resid" = the largest int8 rounding residual
  * of a stored row, default 0.02, beyond which the index answers with the bf16 scan), "rescore_k" (candidates kept by the bf16 scan,
  * 0 = automatic), "nprobe" default for IVF, "id_base" (added to every returned row id:
@@ -159,8 +162,11 @@ int sqe_index_ivf_export(sqe_index* idx, float* centroids_host, int32_t* assign_
  *   SQE_I8_ROW_SCALES  uint32 [tiles * tile_rows]: the integer scale of each row (one value per tile)
  *   SQE_I8_QUERIES     int8 [b_pad][q_pitch]: the quantised queries, row-major (rows >= B are zero)
  *   SQE_I8_THRESHOLDS  int32 [b_pad]: collect threshold of each query on acc * scale
- *   SQE_I8_LIST_COUNTS int32 [n_chunks][b_pad]: keys APPENDED to each (chunk, query) list (> list_cap: the list overflowed)
+ *   SQE_I8_LIST_COUNTS int32 [n_chunks][b_pad]: keys APPENDED to each (chunk, query) list (the first list_cap of them are in the
+ *                      list, the rest went to the query's overflow pool)
  *   SQE_I8_LISTS       uint64 [n_chunks][b_pad][list_cap]: keys, (score ^ 0x80000000) << 32 | (0xFFFFFFFF - row), unordered
+ *   SQE_I8_POOL_COUNTS int32 [b_pad]: keys that found their (chunk, query) list full and went to the query's overflow pool
+ *   SQE_I8_POOLS       uint64 [b_pad][pool_cap]: those keys
  *   SQE_I8_SAMPLE_BEST int32 [sample_chunks][sample_b_pad][8 row lanes][2][2]: threshold pass, the two best (score, row) of each
  *                      lane stream (row lane l of a sampled tile: rows (l >> 2) * 128 + (l & 3) * 4 + 16 i + j, i < 8, j < 4) */
 typedef struct sqe_i8_launch_t {
@@ -176,9 +182,10 @@ typedef struct sqe_i8_launch_t {
     int32_t sample_step;   /* the threshold pass scanned tiles 0, step, 2 step, ... (whole tiles only) */
     int32_t sample_tiles, sample_chunks, sample_b_pad, sample_m;
     int32_t uncertified;   /* queries that went on to the bf16 collect pass (it reuses the list buffers: they are valid only when 0) */
+    int32_t pool_cap;      /* slots of a query's overflow pool */
 } sqe_i8_launch_t;
 enum { SQE_I8_ROWS = 0, SQE_I8_ROW_SCALES = 1, SQE_I8_QUERIES = 2, SQE_I8_THRESHOLDS = 3, SQE_I8_LIST_COUNTS = 4, SQE_I8_LISTS = 5,
-       SQE_I8_SAMPLE_BEST = 6 };
+       SQE_I8_SAMPLE_BEST = 6, SQE_I8_POOL_COUNTS = 7, SQE_I8_POOLS = 8 };
 int sqe_index_i8_last(sqe_index* idx, sqe_i8_launch_t* out);
 int sqe_index_i8_read(sqe_index* idx, int what, int64_t offset, void* out_host, int64_t bytes);
 

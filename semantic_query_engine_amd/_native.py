@@ -37,7 +37,7 @@ class I8Launch(C.Structure):
                 ("k", C.c_int32), ("tile_rows", C.c_int32), ("q_pitch", C.c_int32), ("query_block", C.c_int32),
                 ("n_chunks", C.c_int32), ("list_cap", C.c_int32), ("sample_int8", C.c_int32), ("sample_step", C.c_int32),
                 ("sample_tiles", C.c_int32), ("sample_chunks", C.c_int32), ("sample_b_pad", C.c_int32), ("sample_m", C.c_int32),
-                ("uncertified", C.c_int32)]
+                ("uncertified", C.c_int32), ("pool_cap", C.c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/sqe.h declares

@@ -385,6 +385,12 @@ int sqe_index_set_option(sqe_index* idx, const char* key, double value) {
     } else if (k == "i8_max_resid") {
         if (!(value > 0)) return fail(SQE_ERR_INVALID, "i8_max_resid must be > 0");
         idx->i8_max_resid = value;
+    } else if (k == "i8_anchor_margin") {
+        if (!(value >= 0) || value > 4) return fail(SQE_ERR_INVALID, "i8_anchor_margin must be in [0, 4]");
+        idx->i8_anchor_margin = value;
+    } else if (k == "i8_key_budget") {
+        if (value < 0 || value > 1e9) return fail(SQE_ERR_INVALID, "i8_key_budget must be >= 0");
+        idx->i8_key_budget = (int)value;
     } else if (k == "i8_sample_m") {
         if (value < 1 || value > 64) return fail(SQE_ERR_INVALID, "i8_sample_m must be in [1, 64]");
         idx->i8_sample_m = (int)value;
@@ -634,8 +640,11 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
         SQE_TRY(idx->i8cos_s.ensure((size_t)B * m8 * 4));
         SQE_TRY(idx->i8ids_s.ensure((size_t)B * m8 * 8));
         SQE_TRY(idx->i8stats.ensure(64));
+        SQE_TRY(idx->i8ovf.ensure((size_t)plan.b_pad * I8_OVF_CAP * 8));
+        SQE_TRY(idx->i8ovf_cnt.ensure((size_t)plan.b_pad * 4));
         {
             StageTimer t(c->prof, s, ST_PREP);
+            SQE_HIP(hipMemsetAsync(idx->i8ovf_cnt.p, 0, (size_t)plan.b_pad * 4, s));
             if (b_pad_q > B)
                 SQE_HIP(hipMemsetAsync(idx->q8.as<char>() + (size_t)B * q8_pitch, 0, (size_t)(b_pad_q - B) * q8_pitch, s));
             SQE_TRY(launch_quantize_queries_i8(idx->qn.as<float>(), B, K, idx->q8.as<int8_t>(), q8_pitch, idx->q8sqi.as<uint32_t>(),
@@ -661,6 +670,8 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             ss.sqi = idx->q8sqi.as<uint32_t>(); ss.master = idx->master; ss.qn = idx->qn.as<float>();
             ss.thr_int = idx->i8thr_int.as<int>(); ss.thr_eff = idx->i8thr_eff.as<float>();
             ss.sample_cos = idx->i8cos_s.as<float>(); ss.sample_ids = idx->i8ids_s.as<int64_t>();
+            ss.q_resid8 = idx->q8resid.as<float>(); ss.db_resid8_max = idx->i8resid_max.as<uint32_t>();
+            ss.margin = (float)idx->i8_anchor_margin; ss.step = step8; ss.key_budget = idx->i8_key_budget;
             SQE_TRY(launch_i8_sample_select(ss, s));
         } else {
             // threshold pass: the bf16 scan + fp32 re-score of the row sample, top-m true cosines per query
@@ -692,6 +703,7 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             ia.q8 = idx->q8.as<int8_t>(); ia.q_pitch = q8_pitch; ia.thr_int = idx->i8thr_int.as<int>();
             ia.n_rows = n_rows; ia.K = K; ia.B = B; ia.b_pad = plan.b_pad; ia.n_tiles = plan.n_tiles; ia.n_chunks = plan.n_chunks;
             ia.qblocks = plan.qblocks; ia.bn = plan.bn; ia.cand = idx->cand.as<uint64_t>(); ia.cand_cnt = idx->cand_cnt.as<int>();
+            ia.ovf = idx->i8ovf.as<uint64_t>(); ia.ovf_cnt = idx->i8ovf_cnt.as<int>();
             SQE_TRY(launch_scan_i8(ia, s));
         }
         {
@@ -708,13 +720,14 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             sa.cos_out = cos_out_dev; sa.id_out = id_out_dev; sa.id_base = idx->id_base;
             sa.unc_count = unc_count; sa.collect_thr = collect_thr;
             sa.stats = idx->i8stats.as<unsigned long long>();
+            sa.ovf = idx->i8ovf.as<uint64_t>(); sa.ovf_cnt = idx->i8ovf_cnt.as<int>();
             SQE_TRY(launch_select_i8(sa, s));
         }
         SQE_TRY(run_collect_fallback(idx, B, k, kp, plan.b_pad, unc_count, collect_thr, cos_out_dev, id_out_dev, pass_index, s));
         {
             sqe_i8_launch_t& L = idx->i8_launch;           // what sqe_index_i8_last reports (the uncertified count is read there)
             L.rows = n_rows; L.tile_stride = idx->i8_tile_stride; L.dim = K; L.B = B; L.b_pad = plan.b_pad; L.k = k;
-            L.tile_rows = SCAN_BM; L.q_pitch = q8_pitch; L.query_block = plan.bn; L.n_chunks = plan.n_chunks; L.list_cap = CAND_CAP;
+            L.tile_rows = SCAN_BM; L.q_pitch = q8_pitch; L.query_block = plan.bn; L.n_chunks = plan.n_chunks; L.list_cap = CAND_CAP; L.pool_cap = I8_OVF_CAP;
             L.sample_int8 = sample_i8 ? 1 : 0; L.sample_step = step8; L.sample_tiles = n_tiles_i8s;
             L.sample_chunks = chunks_s_used;
             L.sample_b_pad = b_pad_s; L.sample_m = m8; L.uncertified = -1;
@@ -871,6 +884,8 @@ int sqe_index_i8_read(sqe_index* idx, int what, int64_t offset, void* out_host, 
         case SQE_I8_THRESHOLDS: src = idx->i8thr_int.p; size = (int64_t)L.b_pad * 4; break;
         case SQE_I8_LIST_COUNTS: src = idx->cand_cnt.p; size = (int64_t)L.n_chunks * L.b_pad * 4; break;
         case SQE_I8_LISTS: src = idx->cand.p; size = (int64_t)L.n_chunks * L.b_pad * L.list_cap * 8; break;
+        case SQE_I8_POOL_COUNTS: src = idx->i8ovf_cnt.p; size = (int64_t)L.b_pad * 4; break;
+        case SQE_I8_POOLS: src = idx->i8ovf.p; size = (int64_t)L.b_pad * L.pool_cap * 8; break;
         case SQE_I8_SAMPLE_BEST:
             if (!L.sample_int8) return fail(SQE_ERR_STATE, "sqe_index_i8_read: the threshold pass of the last search did not run in int8");
             src = idx->i8samp.p; size = (int64_t)L.sample_chunks * L.sample_b_pad * 16 * 8; break;

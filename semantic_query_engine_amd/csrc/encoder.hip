@@ -433,9 +433,8 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
 // other does its memory work (4 LDS-DMA pieces, 12 ds_read_b128), one s_barrier per phase (r02's schedule: SHIPPED).
 // Build 512 (tools/build_gpp_ablate.sh 512): ONE s_barrier per half-step (period T_j) instead of one per phase -- the two groups no
 // longer wait for each other in the middle of a period:
-//     G0 (waves 0-3), T_j: issue pieces j + 3 | compute j | vmcnt: own pieces of j + 2 | read operands j + 1 | barrier
+//     G0 (waves 0-3), T_j: compute j | [epilogue] issue pieces j + 3 | vmcnt: own pieces of j + 2 | read operands j + 1 | barrier
 //     G1 (waves 4-7), T_j: [epilogue] issue pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | barrier
-//     (G0's last period of a tile: compute j | epilogue | issue pieces j + 3 | vmcnt | read | barrier)
 // Invariant, as in scan_i8.hip: a piece read in a period was retired by the wave that issued it before a barrier that precedes the
 // read (every wave retires its pieces of x in T_{x-2}; x is read at the end of T_{x-1} and the head of T_x).  r03's form of this
 // schedule had G0 retire its pieces of j + 1 at the head of T_j, behind the barrier -- sibling G0 waves read them unordered, and the
@@ -738,8 +737,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         if (group == 0) {
             read_operands(0);
             for (int e = 0; e < my_tiles; ++e) {
-                issue_next(j);
                 cmp_phase<true>(acc, a, b);
+                issue_next(j);
                 wait_pieces(j);
                 if (j + 1 < J) read_operands(j + 1);
                 GPP_BARRIER();
@@ -747,9 +746,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
                 for (int h = 1; h < HS - 1; ++h) {
                     // (stamps of this form: [3] memory part, [4] barrier, [5] compute part, per steady period)
                     GPP_STAMP(c0);
-                    issue_next(j);
                     cmp_phase<false>(acc, a, b);
                     GPP_STAMP(c1);
+                    issue_next(j);
                     wait_pieces(j);
                     if (j + 1 < J) read_operands(j + 1);
                     GPP_STAMP(c2);

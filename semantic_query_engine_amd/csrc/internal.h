@@ -212,6 +212,9 @@ struct sqe_index {
     int i8_sample_int8 = 1;        // threshold pass: 1 = int8 sample scan + order statistic (r03c), 0 = bf16 scan + fp32 re-score of the sample
     double i8_max_resid = 0.02;    // rows that quantise worse than this (one element 40 x the others: 0.05 at dim 1024) would
                                    //   make every certificate fail: the index then answers with the bf16 scan
+    sqe::DevBuf i8ovf, i8ovf_cnt;  // overflow pool of the collect scan: [b_pad, I8_OVF_CAP] keys, [b_pad] counts (kernels.h)
+    double i8_anchor_margin = 0.25;// the collect threshold never lies above (best true cosine of the sample) - eps (1 + margin): select_i8.hip
+    int i8_key_budget = 6144;      // where the sample predicts that the anchored threshold collects more keys than this, it is not used (0 = no limit)
     sqe_i8_launch_t i8_launch{};   // the last int8 search (sqe_index_i8_last); rows == 0: none yet
     sqe::IvfState* ivf = nullptr;  // kind == SQE_INDEX_IVF_FLAT
     bool internal = false;         // sub-index of another object (IVF coarse quantiser): runs under its owner's lock and stream

@@ -632,6 +632,170 @@ __global__ __launch_bounds__(512) void ivf_list_scan_i8_kernel(const int8_t* __r
     }
 }
 
+// r04: STREAMING form of the int8 list scan -- the rows never touch LDS.  The tiled int8 copy keeps the 64-byte K slice h of
+// tile row r at h * 16 KiB + r * 64, so the A operand of v_mfma_i32_16x16x64_i8 for 16 consecutive rows and one slice -- lane l:
+// row l & 15, bytes (l >> 4) * 16 .. + 15 -- is ONE contiguous KiB: a wave loads it with a single global_load_dwordx4 straight into
+// the operand registers.  No staging ring, no DMA pieces, no workgroup barrier in the loop: every wave streams its own 64 rows of
+// each tile through a register ring of ST_RING fragments (16 KiB in flight per wave; workgroups of four waves, two or more per CU:
+// one loads its queries while the other streams; hipcc counts the vmcnt waits -- the loads are plain loads), and only the few queries
+// that probe the list (8 on average at batch 1024, nprobe 32 of 4096) sit in LDS, loaded once per unit.  The staged kernel above kept 2 x 40 KiB in flight per CU behind one
+// barrier per K step and re-sent the query block with every step: 0.50 of HBM at batch 1024 (profiles/r03_configs/cfg_ivf.json).
+// A workgroup takes one UNIT: up to ST_UNIT_TILES consecutive tiles of one list (table built with the lists), so long lists
+// spread over several CUs and the grid is a few thousand even units.  Strips receive estimated cosines as before.
+constexpr int ST_Q = 32;                  // queries of a list resident in LDS per pass (more: the unit's rows are streamed again)
+constexpr int ST_RING = 16;               // 1-KiB row fragments in flight per wave
+constexpr int ST_FR = 4;                  // fragments (16 rows each) of a wave per K slice: 4 waves x 64 rows = a 256-row tile
+constexpr int ST_SL = ST_RING / ST_FR;    // K slices the ring holds
+constexpr int ST_UNIT_TILES = 4;
+constexpr int ST_THREADS = 256;
+
+// issue cursor of a wave's stream: the next K slice (its ST_FR fragments)
+struct StCursor {
+    const char* tile;                     // base of the cursor's tile (+ the wave's rows)
+    int h;                                // its K slice
+};
+__device__ __forceinline__ void st_issue_slice(StCursor& c, int HS, int64_t tile_stride, unsigned aoff, i32x4_t* r) {
+    const char* p = c.tile + (size_t)c.h * 16384 + aoff;
+#pragma unroll
+    for (int f = 0; f < ST_FR; ++f) {
+#ifdef SQE_ST_NO_NT              // (timing build: default cache policy)
+        r[f] = *reinterpret_cast<const i32x4_t*>(p + f * 1024);
+#else
+        r[f] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(p + f * 1024));
+#endif
+    }
+    if (++c.h == HS) { c.h = 0; c.tile += tile_stride; }
+}
+// ST_SL K slices: the fragments of the ring against the query fragments of slices hb .. hb + ST_SL - 1 (bq: this lane's query
+// row in LDS + hb * 64).  ISSUE: a slice's registers are refilled, as soon as they have been read, with the slice ST_SL ahead.
+// The refill is unconditional inside this body and the LAST group of a unit (ISSUE = false) is code of its own behind the loop: with
+// a branch around the loads hipcc has to assume the path without them at every join and waits for vmcnt(0) in front of each use --
+// the ring drained at every step (first version of this kernel); this way it counts vmcnt(12) in the steady state.
+template <bool ISSUE>
+__device__ __forceinline__ void st_group(i32x4_t (&ring)[ST_RING], i32x4_t (&acc)[ST_FR][2], const char* bq, int qrow, int bcq, int bsw, StCursor& c,
+                                         int HS, int64_t tile_stride, unsigned aoff) {
+#pragma unroll
+    for (int e = 0; e < ST_SL; ++e) {
+        const int boff = ((e * 4 + bcq) ^ bsw) << 4;
+        const i32x4_t b0 = *reinterpret_cast<const i32x4_t*>(bq + boff);
+        const i32x4_t b1 = *reinterpret_cast<const i32x4_t*>(bq + 16 * qrow + boff);
+#pragma unroll
+        for (int f = 0; f < ST_FR; ++f) {
+            acc[f][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[e * ST_FR + f], b0, acc[f][0], 0, 0, 0);
+            acc[f][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[e * ST_FR + f], b1, acc[f][1], 0, 0, 0);
+        }
+        if (ISSUE) st_issue_slice(c, HS, tile_stride, aoff, &ring[e * ST_FR]);
+    }
+}
+
+__global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const int8_t* __restrict__ scan, int64_t tile_stride, const uint32_t* __restrict__ sxi,
+                                                                        const int8_t* __restrict__ qb, int qpitch, const uint32_t* __restrict__ sqi, float unit2,
+                                                                        const int4* __restrict__ units, const int64_t* __restrict__ tile_off,
+                                                                        const int64_t* __restrict__ offsets, const int* __restrict__ lcount,
+                                                                        const int* __restrict__ lq, int cap, int nprobe, int K, int max_len,
+                                                                        float* __restrict__ pair_scores) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int qrow = K + 128;                                  // LDS pitch of a query row: rows r and r + 1 start 32 banks apart
+    float* sscale = reinterpret_cast<float*>(smem + ST_Q * qrow);          // [ST_UNIT_TILES * 256] row scales of the unit
+    int* spair = reinterpret_cast<int*>(sscale + ST_UNIT_TILES * LS_ROWS);
+    float* sqscale = reinterpret_cast<float*>(spair + ST_Q);
+    const int4 u = units[blockIdx.x];
+    const int L = u.x, ntiles = u.z;
+    const int m = min(lcount[L], cap);
+    if (m == 0) return;                                        // nobody probes this list
+    const int len_all = (int)(offsets[L + 1] - offsets[L]);
+    const int row0 = u.y * LS_ROWS;                            // first row of the unit inside its list
+    const int64_t gt0 = tile_off[L] + u.y;                     // ... and its first tile in the copy
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HS = K >> 6;                                     // 64-byte K slices per row (a multiple of ST_SL: the launcher checks)
+    const int GPT = HS / ST_SL;                                // groups per tile
+    // this lane's 16 bytes of a fragment: row (lane & 15) of a 16-row block, bytes (lane >> 4) * 16 of its slice
+    const char* abase = reinterpret_cast<const char*>(scan) + gt0 * tile_stride + wave * (ST_FR * 1024);
+#ifdef SQE_ST_NATURAL            // (timing build, results wrong: lane-contiguous addresses -- what a fragment-major copy would read)
+    const unsigned aoff = (unsigned)(lane * 16);
+#else
+    const unsigned aoff = (unsigned)((lane & 15) * 64 + (lane >> 4) * 16);
+#endif
+    // ... and of a query fragment in LDS: row j * 16 + (lane & 15), chunk (h * 4 + (lane >> 4)) ^ ((row >> 1) & 7)
+    const int br = lane & 15, bsw = (br >> 1) & 7, bcq = lane >> 4;
+    const char* bbase = smem + br * qrow;
+    for (int i = tid; i < ntiles * LS_ROWS; i += ST_THREADS) sscale[i] = (float)sxi[gt0 * LS_ROWS + i];
+
+    for (int g0 = 0; g0 < m; g0 += ST_Q) {
+        const int gq = min(ST_Q, m - g0);
+        __syncthreads();                                       // the previous pass is done with the query block
+        if (tid < ST_Q) {
+            const int pr = lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
+            spair[tid] = pr;
+            sqscale[tid] = unit2 * (float)sqi[pr / nprobe];
+        }
+        __syncthreads();
+        {
+            const int cpr = K >> 4;                            // 16-byte chunks per query row
+            for (int c = tid; c < ST_Q * cpr; c += ST_THREADS) {
+                const int r = c / cpr, cc = c - r * cpr;
+                const i32x4_t v = *reinterpret_cast<const i32x4_t*>(qb + (size_t)(spair[r] / nprobe) * qpitch + cc * 16);
+                *reinterpret_cast<i32x4_t*>(smem + r * qrow + ((cc ^ ((r >> 1) & 7)) << 4)) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- the stream: group g = slices (g % GPT) * ST_SL .. of tile g / GPT; the ring holds group g while group g + 1 is on its way
+        i32x4_t ring[ST_RING];
+        StCursor cur{abase, 0};
+#pragma unroll
+        for (int e = 0; e < ST_SL; ++e) st_issue_slice(cur, HS, tile_stride, aoff, &ring[e * ST_FR]);
+        i32x4_t acc[ST_FR][2];
+#pragma unroll
+        for (int i = 0; i < ST_FR; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+        // scores of a finished tile: a lane holds 4 consecutive rows of one query per fragment
+        auto write_tile = [&](int t) {
+            const int trow = row0 + t * LS_ROWS;               // first row of the tile inside the list
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j * 16 + (lane & 15);
+                if (col < gq) {
+                    float* strip = pair_scores + (size_t)spair[col] * max_len + trow;
+                    const float qs = sqscale[col];
+#pragma unroll
+                    for (int i = 0; i < ST_FR; ++i) {
+                        const int r = wave * (ST_FR * 16) + i * 16 + (lane >> 4) * 4;
+                        if (trow + r < len_all) {              // (strips are padded to 4 floats: max_len)
+                            const f32x4 rs = *reinterpret_cast<const f32x4*>(sscale + t * LS_ROWS + r);
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (float)acc[i][j][e] * rs[e] * qs;
+#ifdef SQE_ST_NO_STORE           // (timing build, results wrong: no strip stores unless a score is NaN)
+                            if (v[0] != v[0])
+#endif
+                            *reinterpret_cast<f32x4*>(strip + r) = v;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < ST_FR; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+        };
+        const int n_grp = ntiles * GPT;
+        int gt = 0, t = 0;                                     // group inside its tile, tile
+        for (int g = 0; g + 1 < n_grp; ++g) {
+            st_group<true>(ring, acc, bbase + gt * ST_SL * 64, qrow, bcq, bsw, cur, HS, tile_stride, aoff);
+            if (++gt == GPT) {
+                write_tile(t);
+                gt = 0;
+                ++t;
+            }
+        }
+        st_group<false>(ring, acc, bbase + gt * ST_SL * 64, qrow, bcq, bsw, cur, HS, tile_stride, aoff);
+        write_tile(t);
+    }
+}
+
 // per query: the kp best scan scores over the strips of its probed lists, re-scored in fp32 against the
 // master, then the top-k by (fp32 cosine desc, row id asc)
 __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
@@ -841,6 +1005,8 @@ struct IvfState {
     int64_t i8_cap = 0, i8_done = 0, total_tiles = 0;    // i8_cap: tiles allocated
     int64_t i8_tile_stride = 0;
     bool use_i8 = true;              // knobs build: SQE_IVF_I8=0 keeps the bf16 list scan (A/B)
+    Buf units4, units1;              // work units of the streaming list scan: (list, first tile in the list, tiles, 0), <= 4 tiles / 1 tile each
+    int n_units4 = 0, n_units1 = 0;
     Buf qn, qb, qd, cent_bf16, cscores, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
 };
@@ -988,6 +1154,22 @@ static int ivf_build_lists(sqe_index* base, IvfState* st, hipStream_t s) {
                                   st->offsets.as<int64_t>(), st->tile_off.as<int64_t>(), st->cursor.as<int>(), st->order.as<int>(),
                                   st->dpos.as<int>());
     SQE_HIP(hipGetLastError());
+    {
+        // work units of the streaming list scan (ivf_list_stream_i8_kernel): runs of <= ST_UNIT_TILES tiles of one list, and single tiles
+        // (the grid of a search with a handful of queries, where few lists are probed and every CU should get some of them)
+        std::vector<int4> u4, u1;
+        for (int i = 0; i < nlist; ++i) {
+            const int nt = (h_counts[i] + 255) / 256;
+            for (int t0 = 0; t0 < nt; t0 += ST_UNIT_TILES) u4.push_back(make_int4(i, t0, std::min(ST_UNIT_TILES, nt - t0), 0));
+            for (int t0 = 0; t0 < nt; ++t0) u1.push_back(make_int4(i, t0, 1, 0));
+        }
+        st->n_units4 = (int)u4.size(); st->n_units1 = (int)u1.size();
+        SQE_TRY(st->units4.ensure(std::max<size_t>(1, u4.size()) * sizeof(int4)));
+        SQE_TRY(st->units1.ensure(std::max<size_t>(1, u1.size()) * sizeof(int4)));
+        if (!u4.empty()) SQE_HIP(hipMemcpyAsync(st->units4.p, u4.data(), u4.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        if (!u1.empty()) SQE_HIP(hipMemcpyAsync(st->units1.p, u1.data(), u1.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        SQE_HIP(hipStreamSynchronize(s));                 // (host vectors)
+    }
     SQE_HIP(hipStreamSynchronize(s));
     st->lists_dirty = false;
     st->i8_done = 0;                                      // the int8 copy follows the list order
@@ -1113,6 +1295,17 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         SQE_TRY(st->q8sqi.ensure((size_t)(B + LS_Q) * 4));
         SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));
         const float unit = i8_scale_unit(dim);
+        static const bool staged = [] { const char* e = knob_env("SQE_IVF_STAGED"); return e && e[0] == '1'; }();   // knobs build: the r03 kernel, for A/B
+        const size_t st_lds = (size_t)ST_Q * (dim + 128) + ST_UNIT_TILES * LS_ROWS * 4 + ST_Q * 8;
+        if (!staged && dim % (64 * ST_SL) == 0 && st_lds <= 64 * 1024 && st->n_units4 > 0) {
+            // streaming form: one workgroup per unit of <= 4 tiles (single tiles when only a handful of lists are probed)
+            const bool few = B * nprobe <= 512;
+            SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_stream_i8_kernel), (int)st_lds));
+            hipLaunchKernelGGL(ivf_list_stream_i8_kernel, dim3(few ? st->n_units1 : st->n_units4), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(),
+                               tile_stride, st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit,
+                               (few ? st->units1 : st->units4).as<int4>(), st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(),
+                               st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len, st->pair_scores.as<float>());
+        } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
         // a handful of queries: pair mode (the kernel's comment), up to 16 workgroups per probed list
         const int n_pairs = B * nprobe <= 512 ? B * nprobe : 0;
@@ -1121,6 +1314,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                            tile_stride, st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit,
                            st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>(), st->probes_ids.as<int64_t>(), n_pairs, split);
+        }
     } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_mfma_kernel), LS_LDS));
         hipLaunchKernelGGL(ivf_list_scan_mfma_kernel, dim3(nlist), dim3(512), LS_LDS, s, base->scan, pitch, st->qb.as<bf16_t>(),

@@ -111,7 +111,12 @@ struct I8ScanArgs {
     int64_t n_rows; int K, B, b_pad, n_tiles, n_chunks, qblocks;
     int bn;                              // queries per workgroup tile: 256 (ping-pong kernel), 128 or 64 (staged kernels, HBM-bound)
     uint64_t* cand; int* cand_cnt;      // the bf16 scan's candidate lists: [n_chunks, b_pad, CAND_CAP], [n_chunks, b_pad]
+    uint64_t* ovf; int* ovf_cnt;        // overflow pool: [b_pad, I8_OVF_CAP] keys that found their (chunk, query) list full, [b_pad] (zeroed by the caller)
 };
+// A (chunk, query) list holds CAND_CAP keys; rows that belong together often sit together (the chunks of one document, a
+// cluster appended in one call), so one query can collect thousands of keys from ONE chunk: what does not fit its list goes to
+// the query's pool (one global atomic per key, rare) and the query stays certifiable.
+constexpr int I8_OVF_CAP = 4096;
 int launch_scan_i8(const I8ScanArgs& args, hipStream_t stream);
 // Threshold pass in int8: every step-th (whole) tile against query blocks of 256; out[chunk][query][16] = the two best
 // (scaled score, row) of each of the 8 row lanes (scan_i8.hip: sample_i8_pp_kernel).  b_pad is a multiple of 256.
@@ -129,6 +134,9 @@ struct I8SampleSelectArgs {
     int m, k, B, b_pad, K;                            // b_pad: padding of thr_int / thr_eff (the collect scan's)
     const uint32_t* sqi; const float* master; const float* qn;
     int* thr_int; float* thr_eff; float* sample_cos; int64_t* sample_ids;
+    // anchor of the threshold on a true cosine (select_i8.hip: i8_sample_select_kernel): the int8 residuals behind eps, the
+    // margin as a fraction of eps, the sampling step (expected keys = sample values above the threshold x step) and the key budget
+    const float* q_resid8; const uint32_t* db_resid8_max; float margin; int step, key_budget;
 };
 int launch_i8_sample_select(const I8SampleSelectArgs& args, hipStream_t stream);
 // Per query: gather the collected keys, fp32 re-score in two stages (the best 64 by int8 score give t = k-th true cosine so
@@ -146,6 +154,7 @@ struct I8SelectArgs {
     float* cos_out; int64_t* id_out; int64_t id_base;
     int* unc_count; float* collect_thr;
     unsigned long long* stats;                                 // null or [4]: keys gathered, rows re-scored, overflows, uncertified
+    const uint64_t* ovf; const int* ovf_cnt;                   // the scan's overflow pool (I8ScanArgs)
 };
 int launch_select_i8(const I8SelectArgs& args, hipStream_t stream);
 

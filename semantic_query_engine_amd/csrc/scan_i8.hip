@@ -45,6 +45,10 @@ constexpr int OFF_CNT = OFF_SCALES + 2 * 1024;     // int [256] list lengths of 
 constexpr int OFF_FLAGS = OFF_CNT + BNQ * 4;       // int [16]
 constexpr int LDS_BYTES = OFF_FLAGS + 64;
 constexpr int BLOCK_BYTES = SCAN_BM * HALF_BYTES;  // 16 KiB: one half-step of a tiled DB tile
+#ifndef SQE_I8_VARIANT
+#define SQE_I8_VARIANT 1
+#endif
+constexpr int I8V = SQE_I8_VARIANT;                // schedule variants of the ping-pong kernel (A/B builds; see g0_head)
 
 struct I8KernelArgs {
     const int8_t* db8;        // tiled int8 copy
@@ -56,7 +60,9 @@ struct I8KernelArgs {
     int64_t n_rows;
     int K, B, b_pad, n_tiles, n_chunks, qblocks;
     uint64_t* cand;           // [n_chunks, b_pad, CAND_CAP]
-    int* cand_cnt;            // [n_chunks, b_pad]: entries APPENDED (may exceed CAND_CAP: the list overflowed)
+    int* cand_cnt;            // [n_chunks, b_pad]: entries APPENDED (beyond CAND_CAP: into the query's overflow pool)
+    uint64_t* ovf;            // [b_pad, I8_OVF_CAP]
+    int* ovf_cnt;             // [b_pad]
     int dbg;
 };
 
@@ -255,7 +261,7 @@ __device__ __forceinline__ int pick_acc_i32(const i32x4 (&acc)[8][4], int t) {
 // append path of one column group of a finished tile (scan_common.h: filter_group, integer scores, no compaction)
 template <int J>
 __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t row_base, int64_t n_rows, bool partial, int qcol, bool live,
-                                              int thr, int scale, int* cnt, uint64_t* cand_base) {
+                                              int thr, int scale, int* cnt, uint64_t* cand_base, uint64_t* ovf_base, int* ovf_cnt) {
     unsigned m = 0;
     // the exact predicate acc * s >= thr (|acc| < 2^23, s < 2^16, product < 2^31: quant.hip)
 #pragma unroll
@@ -287,6 +293,10 @@ __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t 
         if (m & (1u << t)) {
             const int64_t row = row_base + (t >> 2) * 16 + (t & 3);
             if (slot < CAND_CAP) list[slot] = make_key_i32(sc, (uint32_t)row);
+            else {                                  // the list is full: the query's pool (kernels.h: I8_OVF_CAP)
+                const int o = atomicAdd(&ovf_cnt[qcol], 1);
+                if (o < I8_OVF_CAP) ovf_base[(size_t)qcol * I8_OVF_CAP + o] = make_key_i32(sc, (uint32_t)row);
+            }
             ++slot;
         }
     }
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
     P.nt = tile_end - tile_begin;
     P.HS = p.K / 64;
     P.J = P.nt * P.HS;
-    P.tile_bytes = p.tile_stride;
+    P.tile_bytes = (I8V & 32) ? 0 : p.tile_stride;     // (timing build 32: every tile of a chunk reads the chunk's first tile -- L2 hits only, results wrong)
     const size_t ldB = (size_t)p.q_pitch;
 
     int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
@@ -328,6 +338,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
     for (int i = tid; i < BNQ; i += SCAN_THREADS) cnt[i] = 0;
     if (tid < 16) flags[tid] = 0;
     uint64_t* cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    uint64_t* ovf_base = p.ovf + (size_t)q0 * I8_OVF_CAP;
+    int* ovf_cnt = p.ovf_cnt + q0;
     const int q_live = min(BNQ, p.B - q0);
 
     // ---- per-lane DMA source offsets (scan_pp.hip): piece t covers LDS lines 8t .. 8t+7; lane l writes chunk position
@@ -404,10 +416,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 const int64_t row_base = tile_row0 + P.wm * 128 + (fl >> 4) * 4;
                 const bool partial = tile_row0 + SCAN_BM > p.n_rows;
                 const int qc0 = P.wn * 64 + (fl & 15);
-                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base);
-                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base);
-                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base);
-                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base);
+                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
+                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
+                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
+                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (sync_appends) {
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         };
 #ifndef SQE_I8_TWO_BARRIERS
         // ONE barrier per half-step.  Period T_j is what lies between barrier B_{j-1} and barrier B_j:
-        //     G0, T_j: [appends] | issue pieces j + 3 | compute j | vmcnt: own pieces of j + 2 | read operands j + 1 | B_j
+        //     G0, T_j: [appends] | compute j | issue pieces j + 3 | vmcnt: own pieces of j + 2 | read operands j + 1 | B_j
         //     G1, T_j: [appends] | issue pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | B_j
         // INVARIANT (every wave reads lines that all eight waves filled, and nothing but the issuing wave's vmcnt plus a barrier
         // orders a ds_read behind another wave's LDS-DMA): a piece read in period T was retired by the wave that ISSUED it
@@ -441,9 +453,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
             else I8_WAIT(0x0F70);                            // vmcnt(0): nothing was issued in this period
         };
 #ifdef SQE_DEBUG_KNOBS
-        // SQE_I8_DBG (knobs build, A/B of this schedule): 1 G0 issues its pieces BEHIND its compute part (one period of
-        // latency cover instead of two; the invariant holds either way), 4 NO raised priority while computing, 16 appends
-        // before the barrier
+        // SQE_I8_DBG (knobs build, run-time A/B): 4 NO raised priority while computing, 16 appends before the barrier
         const int xdbg = p.dbg >> 3;
 #define I8_PRIO(n) do { if (!(xdbg & 4)) __builtin_amdgcn_s_setprio(n); } while (0)
 #else
@@ -451,16 +461,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         // a wave's compute part runs at raised priority: when both waves of a SIMD have instructions ready, the MFMAs go first
 #define I8_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
-        // G0's half of a period around its compute part
+        // G0's half of a period around its compute part.  I8V (-DSQE_I8_VARIANT=<bits>, tools/build_variant.sh; compile-time: run-time
+        // switches made hipcc spill; the invariant holds in every form): 0 G0 issues its pieces at the HEAD of the period as G1 does
+        // (two periods of latency cover, but all eight waves queue at the address unit at once), 1 (shipped) BEHIND its compute
+        // part (compute | pieces | vmcnt | reads: the two groups' pieces leave at different times; one period of cover is enough),
+        // 2 as 1 with the reads in front of the pieces, 8 G1 reads before it issues.  Measured at 10 M x 1024
+        // (profiles/r04_search/ab_schedule_variants.log), batch 1024 / 256: 0: 9.10-9.16 / 2.62-2.63 ms, 1: 8.44-8.46 / 2.52-2.62,
+        // 2: 8.47-8.52 / 2.53, 9: 8.45-8.49 / 2.57-2.64, 10: 8.40-8.45 / 2.56-2.57.
         auto g0_head = [&](int jj) {
-            if (!(xdbg & 1)) issue_next(jj);
+            if (!(I8V & 3)) issue_next(jj);
         };
         auto g0_tail = [&](int jj) {
-            if (xdbg & 1) issue_next(jj);
+            if (I8V & 2) {
+                if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
+                issue_next(jj);
+                wait_pieces(jj);
+                return;
+            }
+            if (I8V & 1) issue_next(jj);
             wait_pieces(jj);
             if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
         };
         auto g1_head = [&](int jj) {
+            if (I8V & 8) {
+                read_operands(P, a, b, jj);
+                issue_next(jj);
+                return;
+            }
             issue_next(jj);
             read_operands(P, a, b, jj);
         };
@@ -675,7 +702,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
             if (jj + 3 < P.J) I8_WAIT(0x0F74);
             else I8_WAIT(0x0F70);
         };
-        auto g0_tail = [&](int jj) {
+        auto g0_tail = [&](int jj) {                         // behind G0's compute part (scan_i8_pp_kernel: I8V = 1)
+            issue_next(jj);
             wait_pieces(jj);
             if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
         };
@@ -713,13 +741,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sample_i8_pp_kernel(I8SampleKern
         if (group == 0) {
             read_operands(P, a, b, 0);
             for (int e = 0; e < P.nt; ++e) {
-                issue_next(j);
                 cmp_phase<true>(acc, a, b);
                 g0_tail(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS; ++h) {
-                    issue_next(j);
                     cmp_phase<false>(acc, a, b);
                     g0_tail(j);
                     I8_BARRIER();
@@ -901,6 +927,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_small_kernel(I8KernelArg
                         if (live && acc[i][j][r] >= thr[j] && (!partial || row < p.n_rows)) {
                             const int slot = atomicAdd(&cnt[qcol], 1);
                             if (slot < CAND_CAP) list[slot] = make_key_i32(acc[i][j][r], (uint32_t)row);
+                            else {
+                                const int o = atomicAdd(&p.ovf_cnt[q0 + qcol], 1);
+                                if (o < I8_OVF_CAP) p.ovf[(size_t)(q0 + qcol) * I8_OVF_CAP + o] = make_key_i32(acc[i][j][r], (uint32_t)row);
+                            }
                         }
                     }
             }
@@ -942,7 +972,8 @@ int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
     I8KernelArgs k;
     k.db8 = a.db8; k.tile_stride = a.tile_stride; k.sxi = a.sxi; k.q8 = a.q8; k.q_pitch = a.q_pitch; k.thr_int = a.thr_int;
     k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = a.b_pad; k.n_tiles = a.n_tiles; k.n_chunks = a.n_chunks; k.qblocks = a.qblocks;
-    k.cand = a.cand; k.cand_cnt = a.cand_cnt;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.ovf = a.ovf; k.ovf_cnt = a.ovf_cnt;
+    if (!a.ovf || !a.ovf_cnt) return fail(SQE_ERR_INVALID, "int8 scan: no overflow pool");
     {
         static const int force = [] { const char* e = knob_env("SQE_I8_SYNC"); return e ? (e[0] == '0' ? 1 : 2) : 0; }();   // knobs build only
         static const int xdbg = [] { const char* e = knob_env("SQE_I8_DBG"); return e ? atoi(e) : 0; }();

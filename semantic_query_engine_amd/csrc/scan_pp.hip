@@ -466,7 +466,7 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 
 // ONE barrier per half-step (scan_i8.hip has the same loop and the invariant's derivation).  Period T_j lies between barriers
 // B_{j-1} and B_j:
-//     G0, T_j: [tile end] | pieces j + 3 | compute j | vmcnt: own pieces of j + 2 | bound work of j + 1, read operands j + 1 | B_j
+//     G0, T_j: [tile end] | compute j | pieces j + 3 | vmcnt: own pieces of j + 2 | bound work of j + 1, read operands j + 1 | B_j
 //     G1, T_j: [tile end] | bound work of j, pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | B_j
 // INVARIANT: a piece read in period T was retired by the wave that ISSUED it before a barrier that precedes the read -- every
 // wave retires its pieces of half-step x in T_{x-2}, in front of B_{x-2}; x is read at the end of T_{x-1} (G0) and at the head
@@ -476,8 +476,8 @@ __device__ __forceinline__ void mem_any(PP& P, const Filter& f, AOps& a, BOps& b
 // of j + 2, appended keys, and a bound-table fetch (two pieces per wave).  bound_work(x) is what mem_phase() does for the
 // bounds, on the same schedule in x, so every wave's private copy of that state moves alike; G0 runs it behind its compute part,
 // where no operand registers are live (the fold keeps 64 LDS reads in flight; in front of the compute part hipcc spilled).
-//   fetch issued with x = r: G0 at the end of T_{r-1}, retired by its vmcnt(4) at the end of T_r (the pieces of r + 3 are the
-//     four younger entries); G1 at the head of T_r, retired at the end of T_r.  All in front of B_r.
+//   fetch issued with x = r: G0 at the end of T_{r-1} (behind that period's wait), retired by its vmcnt(4) at the end of T_r (the
+//     pieces of r + 3, issued in T_r, are the four younger entries); G1 at the head of T_r, retired at the end of T_r.  All in front of B_r.
 //   fold, x = r + 3: a G0 wave at the end of T_{r+2}, a G1 wave at the head of T_{r+3}: behind B_r.
 //   next fetch, x >= r + 5: from T_{r+4} at the earliest, behind the barrier that follows the fold.
 // Against r02's schedule, a barrier after every phase (-DSQE_PP_TWO_BARRIERS and the STAMPS builds keep it): L2 fills 61.5 ->
@@ -720,8 +720,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bf16_pp_kernel(ScanKernelAr
                 if (jj + 3 < P.J && !P.no_dma) PP_WAIT_VM4();
                 else PP_WAIT_VM0();
             };
-            auto g0_head = [&](int jj) { issue_next(P, jj + 3); };
+            // G0 issues BEHIND its compute part: the two groups' pieces then leave at different times (int8 scan, A/B of the same
+            // choice: -7.5 %, profiles/r04_search/ab_schedule_variants.log); one period of latency cover is enough
+            auto g0_head = [&](int) {};
             auto g0_tail = [&](int jj) {
+                issue_next(P, jj + 3);
                 wait_pieces(jj);
                 if (jj + 1 < P.J) {
                     bound_work(P, f, jj + 1);

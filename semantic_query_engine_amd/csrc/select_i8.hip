@@ -26,8 +26,9 @@ namespace sqe {
 
 namespace {
 
-constexpr int KEY_CAP = 8192;      // collected keys per query held in LDS (~2,000 expected: the sample's threshold is a noisy estimate)
-constexpr int RS_CAP = 2048;       // rows re-scored per query
+constexpr int KEY_CAP = 12288;     // collected keys per query held in LDS (~2,000-3,000 expected; the anchored threshold admits up to the key budget, 6,144
+                                   // PREDICTED keys -- a count of ~60 sample values, +-13 %: twice that fits)
+constexpr int RS_CAP = 4096;       // rows that get a bf16 estimate per query (a whole cluster of near-identical rows: a few thousand)
 constexpr int STAGE1 = 64;
 
 struct SelArgs {
@@ -130,15 +131,16 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
         s_total = 0; s_over = 0; s_min = 0x7fffffff; s_max = (int)0x80000000; s_cutbin = 0; s_n1 = 0; s_n2 = 0; s_n3 = 0; s_kth = 0ull;
     }
     __syncthreads();
-    // ---- gather: one wave per chunk list
-    for (int c = wave; c < p.n_chunks; c += (int)(blockDim.x >> 6)) {
-        int n = p.cand_cnt[(size_t)c * p.b_pad + q];
-        if (n > CAND_CAP) { n = CAND_CAP; if (lane == 0) s_over = 1; }       // the list overflowed: rows were dropped
+    // ---- gather: one wave per chunk list; "chunk" n_chunks is the query's overflow pool (what found its list full)
+    for (int c = wave; c <= p.n_chunks; c += (int)(blockDim.x >> 6)) {
+        const bool pool = c == p.n_chunks;
+        int n = pool ? p.ovf_cnt[q] : min(p.cand_cnt[(size_t)c * p.b_pad + q], CAND_CAP);
+        if (pool && n > I8_OVF_CAP) { n = I8_OVF_CAP; if (lane == 0) s_over = 1; }       // the pool overflowed too: rows were dropped
         if (n <= 0) continue;
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_total, n);
         base = __shfl(base, 0, 64);
-        const uint64_t* list = p.cand + ((size_t)c * p.b_pad + q) * CAND_CAP;
+        const uint64_t* list = pool ? p.ovf + (size_t)q * I8_OVF_CAP : p.cand + ((size_t)c * p.b_pad + q) * CAND_CAP;
         for (int i = lane; i < n; i += 64)
             if (base + i < KEY_CAP) keys[base + i] = list[i];
     }
@@ -394,9 +396,45 @@ __global__ __launch_bounds__(1024) void i8_sample_select_kernel(I8SampleSelectAr
             is[i] = -1;
         }
     }
+    __syncthreads();
+    // ---- the threshold.  Default: the m-th largest sample score (~ step x m rows collected).  The proof select_i8_kernel runs
+    // afterwards is thr_eff + eps < (k-th cosine found); on rows that crowd together -- a cluster whose members are all within
+    // eps of each other: what text embeddings look like -- the m-th sample score lies INSIDE the crowd and the proof fails whatever
+    // the scan collects (r03: every query of the clustered 10 M set took the bf16 pass on top of the int8 one).  The sample's
+    // best row is a real row with a TRUE cosine c0, and the k-th cosine of the index is >= c0 unless the sample caught one of
+    // the top k - 1 rows; so the threshold is ANCHORED: never above c0 - eps (1 + margin).  Then thr_eff + eps <= c0 - margin
+    // eps < k-th cosine: the proof holds by construction, provided the crowd fits the lists.  Whether it fits is estimated from
+    // the sample too (values at or above the threshold x step): where the anchored threshold would collect more than the key
+    // budget, the m-th sample score stands as it did (the best ~ step x m rows by estimate; the proof then fails and the bf16 pass
+    // starts from the k-th cosine found among them).
     if (tid == 0) {
         const double unit = (double)unit0 * (double)p.sqi[q];
         const int t = T > 0 ? key_score_i32(s_mth) : -0x7fffffff;      // no sample: collect everything (the bf16 pass answers)
+        int ta = t;
+        if (kk > 0 && p.q_resid8) {
+            const float eps8 = scan_eps(p.q_resid8[q], __uint_as_float(*p.db_resid8_max), p.K);
+            const float c0 = cs[0];                                    // best true cosine of the sample (written above by this block)
+            const double v = floor(((double)c0 - (double)eps8 * (1.0 + (double)p.margin)) / unit) - 1.0;
+            ta = min(t, v < -2.0e9 ? -0x7fffffff : v > 2.0e9 ? 0x7fffffff : (int)v);
+        }
+        s_min = t;                                                     // (reused: the two thresholds, for the count below)
+        s_cutbin = ta;
+        s_ntop = 0;
+    }
+    __syncthreads();
+    if (s_cutbin < s_min) {
+        const int t = s_cutbin;
+        int mine = 0;
+        for (int i = tid; i < N; i += 1024) mine += (vals[i] != 0ull && key_score_i32(vals[i]) >= t) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        if (lane == 0 && mine) atomicAdd(&s_ntop, mine);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double unit = (double)unit0 * (double)p.sqi[q];
+        const bool too_many = p.key_budget > 0 && (long long)s_ntop * p.step > (long long)p.key_budget;
+        const int t = too_many ? s_min : s_cutbin;
         p.thr_int[q] = t;
         p.thr_eff[q] = (float)((double)t * unit * (1.0 + 1e-6) + 1e-7);   // rounded up (quant.hip: i8_thresholds_kernel)
     }

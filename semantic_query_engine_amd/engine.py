@@ -19,7 +19,7 @@ INDEX_IVF_FLAT = 1
 SCAN_BF16_RESCORE = 0
 SCAN_INT8_RESCORE = 2
 # buffers of the int8 first pass (VectorIndex.i8_read; include/sqe.h: SQE_I8_*)
-I8_ROWS, I8_ROW_SCALES, I8_QUERIES, I8_THRESHOLDS, I8_LIST_COUNTS, I8_LISTS, I8_SAMPLE_BEST = range(7)
+I8_ROWS, I8_ROW_SCALES, I8_QUERIES, I8_THRESHOLDS, I8_LIST_COUNTS, I8_LISTS, I8_SAMPLE_BEST, I8_POOL_COUNTS, I8_POOLS = range(9)
 
 
 def _f32(a: np.ndarray) -> np.ndarray:

@@ -75,17 +75,25 @@ def _expected_keys(acc, scales, thr, row0, rows, B):
 
 
 def _launch_lists(idx, L):
-    """-> (query, key, chunk) of every key the collect launch wrote, and the queries whose lists overflowed"""
+    """-> (query, key, chunk) of every key the collect launch wrote -- its (chunk, query) lists, then the queries' overflow pools
+    (chunk -1: the keys that found their list full) -- and the queries whose POOL overflowed (keys were dropped)"""
     from semantic_query_engine_amd import engine as E
-    nc, bp, cap = L["n_chunks"], L["b_pad"], L["list_cap"]
+    nc, bp, cap, pcap = L["n_chunks"], L["b_pad"], L["list_cap"], L["pool_cap"]
     cnt = idx.i8_read(E.I8_LIST_COUNTS, np.int32, nc * bp).reshape(nc, bp)
     lists = idx.i8_read(E.I8_LISTS, np.uint64, nc * bp * cap).reshape(nc, bp, cap)
-    assert cnt.min() >= 0
-    assert not cnt[:, L["B"]:].any(), "a padding query collected keys"
-    over = np.nonzero((cnt > cap).any(axis=0))[0]
+    pcnt = idx.i8_read(E.I8_POOL_COUNTS, np.int32, bp)
+    assert cnt.min() >= 0 and pcnt.min() >= 0
+    assert not cnt[:, L["B"]:].any() and not pcnt[L["B"]:].any(), "a padding query collected keys"
+    assert np.array_equal(np.maximum(cnt - cap, 0).sum(axis=0), pcnt), "what does not fit a list goes to the pool, nothing else does"
     live = np.arange(cap)[None, None, :] < np.minimum(cnt, cap)[:, :, None]
     c, q, _ = np.nonzero(live)
-    return q.astype(np.int64), lists[live], c, set(over.tolist())
+    q, keys = q.astype(np.int64), lists[live]
+    if pcnt.any():
+        pools = idx.i8_read(E.I8_POOLS, np.uint64, bp * pcap).reshape(bp, pcap)
+        plive = np.arange(pcap)[None, :] < np.minimum(pcnt, pcap)[:, None]
+        pq, _ = np.nonzero(plive)
+        q, keys, c = np.concatenate([q, pq]), np.concatenate([keys, pools[plive]]), np.concatenate([c, np.full(pq.size, -1)])
+    return q, keys, c, set(np.nonzero(pcnt > pcap)[0].tolist())
 
 
 def _check_collect(idx, L, device=None, block_tiles=256):
@@ -102,7 +110,8 @@ def _check_collect(idx, L, device=None, block_tiles=256):
     # every key sits in the list of the chunk that owns its row
     got_row = (0xFFFFFFFF - (got_key & np.uint64(0xFFFFFFFF))).astype(np.int64)
     bounds = np.array([_chunk_range(tiles, L["n_chunks"], c)[0] for c in range(L["n_chunks"])] + [tiles]) * tr
-    assert np.array_equal(np.searchsorted(bounds, got_row, side="right") - 1, got_chunk)
+    in_list = got_chunk >= 0
+    assert np.array_equal((np.searchsorted(bounds, got_row, side="right") - 1)[in_list], got_chunk[in_list])
     exp_q, exp_key = [], []
     first = True
     for t0 in range(0, tiles, block_tiles):
@@ -117,7 +126,7 @@ def _check_collect(idx, L, device=None, block_tiles=256):
         exp_q.append(eq)
         exp_key.append(ek)
     exp_q, exp_key = np.concatenate(exp_q), np.concatenate(exp_key)
-    if over:                                                   # an overflowed list kept an arbitrary subset: those queries are not compared
+    if over:                                                   # an overflowed pool kept an arbitrary subset: those queries are not compared
         assert len(over) <= max(1, B // 50), over
         keep_g, keep_e = ~np.isin(got_q, list(over)), ~np.isin(exp_q, list(over))
         got_q, got_key, exp_q, exp_key = got_q[keep_g], got_key[keep_g], exp_q[keep_e], exp_key[keep_e]

@@ -115,9 +115,9 @@ def test_bf16_threshold_pass_option(ctx, b):
 
 def test_identical_calls_collect_the_same_keys(ctx):
     """The number of keys the int8 scan collects is a function of EVERY estimated score against a fixed threshold: it must not
-    move between identical calls.  (It did, by a few keys in two million, while a wave read its operands right behind its own
-    MFMAs / right behind its own counted wait: scan_i8.hip, mfma_operand_guard and g0_wait; tests/dbg_scan_repeat.py is the
-    long form of this test.)"""
+    move between identical calls.  (r03's one-barrier schedule let group 0 retire its DMA pieces behind the barrier its sibling
+    waves' reads relied on, and this count moved by a few keys in two million; tests/test_i8_exact_gpu.py now checks one launch
+    bit for bit against NumPy, this test keeps the repeated-call symptom; tools/repeat_scan.py is its long form.)"""
     n, d, b, k = 600_000, 1024, 700, 10
     rng = np.random.default_rng(17)
     x = rng.standard_normal((n, d), dtype=np.float32)
@@ -160,18 +160,68 @@ def test_near_ties_at_the_kth_place(ctx):
     idx.close()
 
 
-def test_clustered_rows_fall_back_and_stay_exact(ctx):
-    """Tightly clustered rows: thousands of rows sit inside the int8 error band of the k-th place, the certificate
-    fails (or the lists overflow) and the bf16 collect pass answers.  Still the exact top-k."""
+@pytest.mark.parametrize("anchored", [True, False])
+def test_clustered_rows_stay_exact(ctx, anchored):
+    """Tightly clustered rows: ~2,000 rows sit inside the int8 error band of the k-th place.  With the threshold anchored on the
+    sample's best true cosine (select_i8.hip: i8_sample_select_kernel) the scan collects the whole crowd and the certificate holds
+    by construction; without the anchor (key budget 1: it is never used -- r03's behaviour) the m-th sample score lies inside the
+    crowd, the proof fails and the bf16 collect pass answers.  The exact top-k either way."""
     rng = np.random.default_rng(23)
     d, n, b, k = 256, 80000, 300, 10
     cen = rng.standard_normal((40, d)).astype(np.float32)
     x = (cen[rng.integers(0, 40, n)] + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
     q = (cen[rng.integers(0, 40, b)] + 0.05 * rng.standard_normal((b, d))).astype(np.float32)
     idx = _i8_index(ctx, d, step=4)
+    if not anchored:
+        idx.set_option("i8_key_budget", 1)
     idx.add(x)
     cos, ids, st = _check(ctx, idx, x, q, k, tol=5e-6)
-    assert st["uncertified"] > 0                             # this data is what the fallback is for
+    if anchored:
+        assert st["uncertified"] <= b // 20 and st["i8_overflows"] <= b // 20, st
+        assert st["i8_collected"] > 1000 * b, st             # the crowds were collected whole
+    else:
+        assert st["uncertified"] > 0                         # this data is what the fallback is for
+    idx.close()
+
+
+def test_text_like_clusters_certify_in_the_int8_pass(ctx):
+    """SURVEY 8(d)'s clustered set in small: Gaussian centres, rows = centre + 0.3 x noise, ~2,400 rows per centre -- what text
+    embeddings look like.  Every member of the query's cluster lies within the int8 bound of the 10th place (in-cluster cosines
+    0.917 +- 0.003 against eps ~0.02); r03 paid the int8 pass and then the bf16 pass for every such query.  The anchored threshold
+    falls into the gap below the cluster, the int8 pass certifies."""
+    rng = np.random.default_rng(29)
+    d, n, b, k, ncen = 1024, 240_000, 256, 10, 100
+    cen = rng.standard_normal((ncen, d)).astype(np.float32)
+    x = cen[rng.integers(0, ncen, n)] + 0.3 * rng.standard_normal((n, d), dtype=np.float32)
+    q = cen[rng.integers(0, ncen, b)] + 0.3 * rng.standard_normal((b, d), dtype=np.float32)
+    idx = _i8_index(ctx, d, step=8, m=20)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k, tol=5e-6)
+    assert st["uncertified"] <= b // 50 and st["i8_overflows"] == 0, st
+    assert 1500 * b < st["i8_collected"] < 4000 * b, st      # ~ one cluster per query
+    idx.close()
+
+
+def test_a_crowd_in_one_chunk_goes_through_the_overflow_pool(ctx):
+    """3,000 near-identical rows appended in ONE call (the chunks of one document, a cluster added at once) sit in one or two row
+    chunks: a query aimed at them collects thousands of keys from a (chunk, query) list of 512 slots.  What does not fit goes to
+    the query's overflow pool (kernels.h: I8_OVF_CAP) and the int8 pass still certifies (r03: list overflow -> bf16 pass)."""
+    rng = np.random.default_rng(37)
+    d, n, b, k, crowd = 512, 200_000, 300, 10, 3000
+    x = rng.standard_normal((n + crowd, d), dtype=np.float32)
+    centre = rng.standard_normal((1, d), dtype=np.float32)
+    x[n:] = centre + 3e-3 * rng.standard_normal((crowd, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    q[:8] = centre + 3e-3 * rng.standard_normal((8, d), dtype=np.float32)
+    idx = _i8_index(ctx, d, step=8, m=20)
+    idx.add(x)
+    cos, ids, st = _check(ctx, idx, x, q, k, tol=5e-6)
+    assert np.all(ids[:8] >= n)
+    assert st["uncertified"] <= 2 and st["i8_overflows"] == 0, st
+    from semantic_query_engine_amd import engine as E
+    L = idx.i8_last()
+    pool = idx.i8_read(E.I8_POOL_COUNTS, np.int32, L["b_pad"])
+    assert np.all(pool[:8] > 1000) and not pool[8:].any(), pool[:12]
     idx.close()
 
 
@@ -231,9 +281,9 @@ def test_a_row_that_quantises_badly_switches_the_index_to_bf16(ctx):
     idx.add(onehot)
     _, _, st = _check(ctx, idx, x2, q, k, want_i8=False)
     assert st["i8_collected"] == 0                                        # the bf16 scan answered
-    idx.set_option("i8_max_resid", 1.0)                                   # forced: int8 pass, every proof fails, bf16 pass -- still exact
+    idx.set_option("i8_max_resid", 1.0)                                   # forced: int8 pass, (almost) every proof fails, bf16 pass -- still exact
     _, _, st = _check(ctx, idx, x2, q, k)
-    assert st["uncertified"] == b
+    assert st["uncertified"] >= b * 3 // 4, st                            # (the anchored threshold still certifies a few queries)
     idx.close()
 
 

@@ -1,5 +1,5 @@
 """One-layer BERT-large-geometry encode of 32 x 512 tokens against the oracle: NaN rows, max |diff|, min cosine.
-usage (GPU box, repo root): [SQE_LIB=...libsqe_knobs.so SQE_ENC_GEMM=0|1] python tests/dbg_enc.py   (the check behind
+usage (GPU box, repo root): [SQE_LIB=...libsqe_knobs.so SQE_ENC_GEMM=0|1] python tools/enc_one_layer.py   (the check behind
 tests/test_encoder_gpu.py::test_large_batch_persistent_gemms, as a script for bisecting a GEMM kernel)"""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())

@@ -1,5 +1,5 @@
-"""Debug helper (not a test): encode the same 64 x S ragged batch many times and compare the outputs bit for bit.
-usage (GPU box): python tests/dbg_enc_repeat.py [S] [repeats]"""
+"""Hand-run check (not a test): encode the same 64 x S ragged batch many times and compare the outputs bit for bit.
+usage (GPU box): python tools/repeat_enc.py [S] [repeats]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
-"""Debug helper (not a test): the same int8 search many times -- the number of collected keys is a function of every estimated
-score against a fixed threshold, so it must not change between identical calls.  usage (GPU box): python tests/dbg_scan_repeat.py"""
+"""Hand-run check (not a test): the same int8 search many times -- the number of collected keys is a function of every estimated
+score against a fixed threshold, so it must not change between identical calls.  usage (GPU box): python tools/repeat_scan.py [rows] [repeats]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
