@@ -114,10 +114,13 @@ def load() -> C.CDLL:
     # copies first and torch is imported later, the process holds two HIP runtimes and torch's finds no device
     # (hipErrorNoDevice at its first CUDA call).  With torch loaded first the dynamic linker binds libsqe.so to the
     # copies already in the process (same SONAMEs).  Nothing of torch is used here.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # A caller that never imports torch (a plain ctypes / NumPy host) can skip the multi-second import: SQE_NO_TORCH_PRELOAD=1.
+    import sys
+    if "torch" not in sys.modules and os.environ.get("SQE_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

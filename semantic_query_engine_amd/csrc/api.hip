@@ -704,7 +704,36 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
             ia.n_rows = n_rows; ia.K = K; ia.B = B; ia.b_pad = plan.b_pad; ia.n_tiles = plan.n_tiles; ia.n_chunks = plan.n_chunks;
             ia.qblocks = plan.qblocks; ia.bn = plan.bn; ia.cand = idx->cand.as<uint64_t>(); ia.cand_cnt = idx->cand_cnt.as<int>();
             ia.ovf = idx->i8ovf.as<uint64_t>(); ia.ovf_cnt = idx->i8ovf_cnt.as<int>();
+            static const bool want_stamps = [] { const char* e = knob_env("SQE_I8_STAMPS"); return e && e[0] == '1'; }();   // knobs build only
+            if (want_stamps) {
+                SQE_TRY(idx->dbg.ensure(8192));
+                SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 8192, s));
+                ia.stamps = idx->dbg.as<unsigned long long>();
+            }
             SQE_TRY(launch_scan_i8(ia, s));
+            if (want_stamps) {
+                unsigned long long h[256];
+                SQE_HIP(hipMemcpyAsync(h, idx->dbg.p, sizeof(h), hipMemcpyDeviceToHost, s));
+                SQE_HIP(hipStreamSynchronize(s));
+                int wall_khz = 0;
+                (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device);
+                for (int blk = 0; blk < 2; ++blk) {
+                    const unsigned long long* o = h + blk * 128;
+                    int prev = -1;
+                    for (int sl = 0; sl < 32; ++sl) {
+                        if (!o[sl * 3]) continue;
+                        if (prev >= 0 && o[sl * 3] > o[prev * 3]) {
+                            const double tiles = (double)(o[sl * 3] - o[prev * 3]);
+                            const double us = (double)(o[sl * 3 + 1] - o[prev * 3 + 1]) / (wall_khz / 1e3);
+                            const double cyc = (double)(o[sl * 3 + 2] - o[prev * 3 + 2]);
+                            fprintf(stderr, "[sqe i8 stamps] wg %3d tiles %5llu..%5llu: %7.2f us per tile, %7.0f core cycles per tile, %5.0f MHz\n",
+                                    blk ? 100 : 0, o[prev * 3], o[sl * 3], us / tiles, cyc / tiles, us > 0 ? cyc / us : 0.0);
+                        }
+                        prev = sl;
+                    }
+                }
+                idx->dbg.release();
+            }
         }
         {
             StageTimer t(c->prof, s, ST_SELECT);

@@ -430,22 +430,25 @@ int launch_gemm_persistent(const GemmArgs& a, int t_pad, int cu_count, hipStream
 // Large-batch form, ping-pong schedule (the flat scan's, scan_pp.hip, with an epilogue where the scan has its
 // filter): 256 x 256 tiles, PERSISTENT workgroups, K in 32-wide half-steps through a 4-stage LDS ring, the two
 // waves of a SIMD taking turns at the matrix pipe: while one computes a half-step (32 MFMAs on registers) the
-// other does its memory work (4 LDS-DMA pieces, 12 ds_read_b128), one s_barrier per phase (r02's schedule: SHIPPED).
-// Build 512 (tools/build_gpp_ablate.sh 512): ONE s_barrier per half-step (period T_j) instead of one per phase -- the two groups no
-// longer wait for each other in the middle of a period:
+// other does its memory work (4 LDS-DMA pieces, 12 ds_read_b128).
+// Schedule (r04, shipped): ONE s_barrier per half-step (period T_j) instead of r02's one per phase -- the two groups no longer wait for
+// each other in the middle of a period:
 //     G0 (waves 0-3), T_j: compute j | [epilogue] issue pieces j + 3 | vmcnt: own pieces of j + 2 | read operands j + 1 | barrier
 //     G1 (waves 4-7), T_j: [epilogue] issue pieces j + 3 | read operands j | compute j | vmcnt: own pieces of j + 2 | barrier
 // Invariant, as in scan_i8.hip: a piece read in a period was retired by the wave that issued it before a barrier that precedes the
 // read (every wave retires its pieces of x in T_{x-2}; x is read at the end of T_{x-1} and the head of T_x).  r03's form of this
-// schedule had G0 retire its pieces of j + 1 at the head of T_j, behind the barrier -- sibling G0 waves read them unordered, and the
-// output of 64 x 512 tokens changed in a row or two between identical calls.  An epilogue always stands in FRONT of its period's
-// pieces, so the plain vmcnt(4) behind them covers its stores (operations retire in issue order).
+// schedule had G0 retire its pieces of j + 1 at the head of T_j, behind the barrier -- sibling G0 waves read them unordered, the
+// output of 64 x 512 tokens changed in a row or two between identical calls (7 of 30), and r03 shipped r02's schedule instead.  On
+// the corrected schedule: 0 of 12 repeats at 64 x 512 tokens and 0 of 40 at 64 x 128 differ (tools/repeat_enc.py), 24.09-24.14 ->
+// 23.70-23.74 ms for the encode of 64 x 512 tokens (profiles/r04_configs/enc_one_barrier_ab.log).  An epilogue always stands in
+// FRONT of its period's pieces, so the plain vmcnt(4) behind them covers its stores (operations retire in issue order).
+// Build 512 (tools/build_gpp_ablate.sh 512) keeps r02's schedule for A/B.
 namespace gpp {
 // Ablation builds of the ping-pong GEMM (tools/build_gpp_ablate.sh <bits>, timing only, results wrong): 8 = no DMA pieces,
 // 16 = no operand reads, 32 = no epilogue, 64 = every tile reads the operands of tile 0 (always in L2), 128 = the pieces of a
 // half-step read whole 128-B lines of 128 rows instead of 64-B halves of 256 rows (the same bytes per tile), 256 = a 5-stage
-// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it (not together with 512); 512 = the
-// one-barrier schedule described above.  Compile-time, so
+// ring (four half-steps in flight) over all 160 KiB, the bias vector read from inside it; 512 = r02's schedule, a barrier after
+// every phase.  Compile-time, so
 // that the shipped kernel's register allocation is the one measured (run-time switches made hipcc spill).
 #ifndef SQE_GPP_ABLATE
 #define SQE_GPP_ABLATE 0
@@ -720,8 +723,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     unsigned long long k0 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, c0 = 0, c1 = 0, c2 = 0, clk[8] = {};
 #endif
     GPP_STAMP(k0);
-    if (GPP_ABLATE & 512) {
-        // Build 512: one barrier per half-step (the schedule and its invariant: comment above the kernel, scan_i8.hip)
+    static_assert(!(GPP_ABLATE & 256) || (GPP_ABLATE & 512), "the five-stage ring experiment runs on r02's schedule: build 768");
+    if (!(GPP_ABLATE & 512)) {
+        // SHIPPED (r04): one barrier per half-step (the schedule and its invariant: comment above the kernel, scan_i8.hip); build 512
+        // keeps r02's loop, a barrier after every phase, below
         auto issue_next = [&](int jj) {
             if (jj + 3 < J && !(GPP_ABLATE & 8)) {
                 issue(dm, (jj + 3) & 3);

@@ -648,6 +648,8 @@ constexpr int ST_FR = 4;                  // fragments (16 rows each) of a wave 
 constexpr int ST_SL = ST_RING / ST_FR;    // K slices the ring holds
 constexpr int ST_UNIT_TILES = 4;
 constexpr int ST_THREADS = 256;
+constexpr int ST_PATCH_PITCH = 68;        // floats per query row of a wave's transpose patch: 64 rows + 4 (16-byte rows of different queries on different banks)
+constexpr int ST_PATCH_ROWS = 36;         // query rows of patch per wave: four tiles of <= 8 (padded: 9) queries, one tile of 32
 
 // issue cursor of a wave's stream: the next K slice (its ST_FR fragments)
 struct StCursor {
@@ -699,6 +701,8 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
     float* sscale = reinterpret_cast<float*>(smem + ST_Q * qrow);          // [ST_UNIT_TILES * 256] row scales of the unit
     int* spair = reinterpret_cast<int*>(sscale + ST_UNIT_TILES * LS_ROWS);
     float* sqscale = reinterpret_cast<float*>(spair + ST_Q);
+    // per wave: ST_PATCH_ROWS query rows of [64 rows + 4] floats: the transposed scores of finished tiles, waiting for their stores
+    float* spatch = sqscale + ST_Q + (threadIdx.x >> 6) * (ST_PATCH_ROWS * ST_PATCH_PITCH);
     const int4 u = units[blockIdx.x];
     const int L = u.x, ntiles = u.z;
     const int m = min(lcount[L], cap);
@@ -751,31 +755,56 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
         for (int i = 0; i < ST_FR; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
-        // scores of a finished tile: a lane holds 4 consecutive rows of one query per fragment
-        auto write_tile = [&](int t) {
-            const int trow = row0 + t * LS_ROWS;               // first row of the tile inside the list
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = j * 16 + (lane & 15);
-                if (col < gq) {
-                    float* strip = pair_scores + (size_t)spair[col] * max_len + trow;
-                    const float qs = sqscale[col];
-#pragma unroll
-                    for (int i = 0; i < ST_FR; ++i) {
-                        const int r = wave * (ST_FR * 16) + i * 16 + (lane >> 4) * 4;
-                        if (trow + r < len_all) {              // (strips are padded to 4 floats: max_len)
-                            const f32x4 rs = *reinterpret_cast<const f32x4*>(sscale + t * LS_ROWS + r);
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (float)acc[i][j][e] * rs[e] * qs;
+        // Scores of a finished tile.  A lane holds 4 consecutive rows of ONE query per fragment: the wave transposes its 64 rows x gq
+        // queries through a private LDS patch, so that 16 lanes hold the 256 contiguous bytes of one query's 64 rows (four queries per
+        // store instruction).  WHEN the stores leave matters more than their shape: vector-memory operations retire in issue order, so a
+        // row fragment loaded behind a store cannot be consumed before that store has been acknowledged -- a stall of one store latency
+        // per tile (measured: 2.03 ms with the stores behind every tile, in 64-byte segments or 256-byte runs alike, 1.61 ms without
+        // stores; profiles/r04_configs/ivf_stream_ablation.log).  The patches of up to four tiles therefore wait in LDS (as many as fit:
+        // 36 query rows of 64 scores per wave) and leave together -- for the usual handful of probing queries once per unit, behind
+        // its last load.
+        const int gq_pad = (gq + 3) & ~3;
+        const int max_slots = ST_PATCH_ROWS / gq_pad;          // tiles whose patches fit (gq <= 32: at least one)
+        int nslot = 0, slot_t0 = 0;
+        auto flush = [&]() {
+            const int r4 = (lane & 15) * 4;                    // this lane's 4 rows of the wave's 64
+            for (int sl = 0; sl < nslot; ++sl) {
+                const int wrow = row0 + (slot_t0 + sl) * LS_ROWS + wave * (ST_FR * 16) + r4;   // row inside the list
+                const float* patch = spatch + sl * gq_pad * ST_PATCH_PITCH;
+                for (int c0 = 0; c0 < gq; c0 += 4) {
+                    const int col = c0 + (lane >> 4);
+                    if (col < gq && wrow < len_all) {          // (strips are padded to 4 floats: max_len)
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + col * ST_PATCH_PITCH + r4);
 #ifdef SQE_ST_NO_STORE           // (timing build, results wrong: no strip stores unless a score is NaN)
-                            if (v[0] != v[0])
+                        if (v[0] != v[0])
 #endif
-                            *reinterpret_cast<f32x4*>(strip + r) = v;
-                        }
+                        *reinterpret_cast<f32x4*>(pair_scores + (size_t)spair[col] * max_len + wrow) = v;
                     }
                 }
             }
+            nslot = 0;
+        };
+        auto write_tile = [&](int t, bool last) {
+            if (nslot == 0) slot_t0 = t;
+            float* patch = spatch + nslot * gq_pad * ST_PATCH_PITCH;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j * 16 + (lane & 15);
+                if (col < gq_pad) {
+                    const float qs = sqscale[col];
+#pragma unroll
+                    for (int i = 0; i < ST_FR; ++i) {
+                        const int r = i * 16 + (lane >> 4) * 4;    // row inside the wave's 64
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(sscale + t * LS_ROWS + wave * (ST_FR * 16) + r);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)acc[i][j][e] * rs[e] * qs;
+                        *reinterpret_cast<f32x4*>(patch + col * ST_PATCH_PITCH + r) = v;
+                    }
+                }
+            }
+            // (wave-private patches: the LDS operations of a wave execute in order, no barrier)
+            if (++nslot == max_slots || last) flush();
 #pragma unroll
             for (int i = 0; i < ST_FR; ++i)
 #pragma unroll
@@ -786,13 +815,13 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
         for (int g = 0; g + 1 < n_grp; ++g) {
             st_group<true>(ring, acc, bbase + gt * ST_SL * 64, qrow, bcq, bsw, cur, HS, tile_stride, aoff);
             if (++gt == GPT) {
-                write_tile(t);
+                write_tile(t, false);
                 gt = 0;
                 ++t;
             }
         }
         st_group<false>(ring, acc, bbase + gt * ST_SL * 64, qrow, bcq, bsw, cur, HS, tile_stride, aoff);
-        write_tile(t);
+        write_tile(t, true);
     }
 }
 
@@ -810,15 +839,27 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
     auto key_at = [&](int p, int i, int64_t off) {
         return make_key(pair_scores[((size_t)q * nprobe + p) * max_len + i], (uint32_t)order[off + i]);
     };
-    // total number of probed rows
-    int total = 0;
-    for (int p = 0; p < nprobe; ++p) {
+    // the query's probed lists into LDS once (r04: every pass below used to re-read probes / offsets list by list, a chain of
+    // dependent loads per list; batch 1024: 476 us for the kernel)
+    __shared__ int s_len[MAX_KP];
+    __shared__ int64_t s_off[MAX_KP];
+    __shared__ int s_total;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    for (int p = tid; p < nprobe; p += 256) {
         const int64_t L = probes[(size_t)q * nprobe + p];
-        if (L >= 0) total += (int)(offsets[L + 1] - offsets[L]);
+        const int64_t off = L >= 0 ? offsets[L] : 0;
+        const int len = L >= 0 ? (int)(offsets[L + 1] - off) : 0;
+        s_off[p] = off;
+        s_len[p] = len;
+        if (len) atomicAdd(&s_total, len);
     }
+    __syncthreads();
+    const int total = s_total;                       // total number of probed rows
+    const int wave4 = tid >> 6, lane64 = tid & 63;
     // ---- fast path: a threshold from a strided sample, ONE pass over the strips that collects every key
     // at or above it, exact top-kp among the few collected.  (The general path below walks the strips
-    // eight times; it remains the fallback when the sample misjudges the tail.)
+    // eight times; it remains the fallback when the sample misjudges the tail.)  One wave per strip in both passes.
     constexpr int SAMPLE_CAP = 8704, COLLECT_CAP = 1024;
     __shared__ uint32_t sample[SAMPLE_CAP];
     __shared__ uint64_t coll[COLLECT_CAP];
@@ -827,12 +868,10 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         const int stride = (total + 8191) / 8192;
         if (tid == 0) { scratch[0] = 0; scratch[2] = 0; }
         __syncthreads();
-        for (int p = 0; p < nprobe; ++p) {
-            const int64_t L = probes[(size_t)q * nprobe + p];
-            if (L < 0) continue;
-            const int len = (int)(offsets[L + 1] - offsets[L]);
+        for (int p = wave4; p < nprobe; p += 4) {
+            const int len = s_len[p];
             const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
-            for (int i = tid * stride + (p % stride); i < len; i += 256 * stride) {
+            for (int i = lane64 * stride + (p % stride); i < len; i += 64 * stride) {
                 const float sc = strip[i];
                 if (sc != sc) continue;
                 const int slot = atomicAdd(&scratch[0], 1);
@@ -869,17 +908,19 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
             }
             thr = pre;
         }
-        for (int p = 0; p < nprobe; ++p) {
-            const int64_t L = probes[(size_t)q * nprobe + p];
-            if (L < 0) continue;
-            const int64_t off = offsets[L];
-            const int len = (int)(offsets[L + 1] - off);
-            const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
-            for (int i = tid; i < len; i += 256) {
-                const float sc = strip[i];
-                if (sc == sc && f32_orderable(sc + 0.0f) >= thr) {
-                    const int slot = atomicAdd(&scratch[2], 1);
-                    if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)order[off + i]);
+        for (int p = wave4; p < nprobe; p += 4) {
+            const int len = s_len[p];
+            const int64_t off = s_off[p];
+            const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;   // (16-byte aligned: max_len is a multiple of 4)
+            for (int i = lane64 * 4; i < len; i += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(strip + i);           // (strips are padded to 4 floats)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = v[e];
+                    if (i + e < len && sc == sc && f32_orderable(sc + 0.0f) >= thr) {
+                        const int slot = atomicAdd(&scratch[2], 1);
+                        if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)order[off + i + e]);
+                    }
                 }
             }
         }
@@ -1296,8 +1337,8 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));
         const float unit = i8_scale_unit(dim);
         static const bool staged = [] { const char* e = knob_env("SQE_IVF_STAGED"); return e && e[0] == '1'; }();   // knobs build: the r03 kernel, for A/B
-        const size_t st_lds = (size_t)ST_Q * (dim + 128) + ST_UNIT_TILES * LS_ROWS * 4 + ST_Q * 8;
-        if (!staged && dim % (64 * ST_SL) == 0 && st_lds <= 64 * 1024 && st->n_units4 > 0) {
+        const size_t st_lds = (size_t)ST_Q * (dim + 128) + ST_UNIT_TILES * LS_ROWS * 4 + ST_Q * 8 + (ST_THREADS / 64) * ST_PATCH_ROWS * ST_PATCH_PITCH * 4;
+        if (!staged && dim % (64 * ST_SL) == 0 && st_lds <= 80 * 1024 && st->n_units4 > 0) {      // (two workgroups per CU)
             // streaming form: one workgroup per unit of <= 4 tiles (single tiles when only a handful of lists are probed)
             const bool few = B * nprobe <= 512;
             SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_stream_i8_kernel), (int)st_lds));

@@ -112,6 +112,7 @@ struct I8ScanArgs {
     int bn;                              // queries per workgroup tile: 256 (ping-pong kernel), 128 or 64 (staged kernels, HBM-bound)
     uint64_t* cand; int* cand_cnt;      // the bf16 scan's candidate lists: [n_chunks, b_pad, CAND_CAP], [n_chunks, b_pad]
     uint64_t* ovf; int* ovf_cnt;        // overflow pool: [b_pad, I8_OVF_CAP] keys that found their (chunk, query) list full, [b_pad] (zeroed by the caller)
+    unsigned long long* stamps = nullptr;   // knobs build: 256 x u64, zeroed (scan_i8.hip: tile_end)
 };
 // A (chunk, query) list holds CAND_CAP keys; rows that belong together often sit together (the chunks of one document, a
 // cluster appended in one call), so one query can collect thousands of keys from ONE chunk: what does not fit its list goes to

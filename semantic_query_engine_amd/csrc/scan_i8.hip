@@ -37,18 +37,22 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int HALF_BYTES = 64;                     // bytes per row per half-step (64 int8 elements)
 constexpr int LINE_BYTES = 128;                    // LDS line: the slices of tile rows L and L + 128
 constexpr int OPER_BYTES = 128 * LINE_BYTES;       // 16 KiB: one operand of one half-step
-constexpr int STAGE_BYTES = 2 * OPER_BYTES;        // DB rows, then queries
 constexpr int NSTAGE = 4;
 constexpr int BNQ = 256;
-constexpr int OFF_SCALES = NSTAGE * STAGE_BYTES;   // 2 x [256] u32 row scales (tile parity)
-constexpr int OFF_CNT = OFF_SCALES + 2 * 1024;     // int [256] list lengths of this workgroup's queries
-constexpr int OFF_FLAGS = OFF_CNT + BNQ * 4;       // int [16]
-constexpr int LDS_BYTES = OFF_FLAGS + 64;
-constexpr int BLOCK_BYTES = SCAN_BM * HALF_BYTES;  // 16 KiB: one half-step of a tiled DB tile
 #ifndef SQE_I8_VARIANT
 #define SQE_I8_VARIANT 1
 #endif
 constexpr int I8V = SQE_I8_VARIANT;                // schedule variants of the ping-pong kernel (A/B builds; see g0_head)
+// LDS: a ring of NSTA stages for the DB rows, then a ring of NSTAGE stages for the queries.  I8V & 64 (A/B build): FIVE row stages --
+// the rows of half-step x are issued in T_{x-4} instead of T_{x-3}, one more period of HBM latency cover, the queries (L2 hits) as before
+constexpr int NSTA = (I8V & 64) ? 5 : NSTAGE;
+constexpr int OFF_B = NSTA * OPER_BYTES;
+constexpr int OFF_SCALES = OFF_B + NSTAGE * OPER_BYTES;   // 2 x [256] u32 row scales (tile parity)
+constexpr int OFF_CNT = OFF_SCALES + 2 * 1024;     // int [256] list lengths of this workgroup's queries
+constexpr int OFF_FLAGS = OFF_CNT + BNQ * 4;       // int [16]
+constexpr int LDS_BYTES = OFF_FLAGS + 64;
+constexpr int BLOCK_BYTES = SCAN_BM * HALF_BYTES;  // 16 KiB: one half-step of a tiled DB tile
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct I8KernelArgs {
     const int8_t* db8;        // tiled int8 copy
@@ -63,6 +67,7 @@ struct I8KernelArgs {
     int* cand_cnt;            // [n_chunks, b_pad]: entries APPENDED (beyond CAND_CAP: into the query's overflow pool)
     uint64_t* ovf;            // [b_pad, I8_OVF_CAP]
     int* ovf_cnt;             // [b_pad]
+    unsigned long long* stamps;   // knobs build, SQE_I8_STAMPS=1: (constant-rate clock, core clock) of workgroups 0 and 100 at tiles 0, 1, 2, 4, 8, ...
     int dbg;
 };
 
@@ -114,13 +119,13 @@ struct S8 {
         }
     }
     __device__ __forceinline__ void issue_a(const Cur& c, int stage) const {
-        char* st = smem + stage * STAGE_BYTES;
+        char* st = smem + stage * OPER_BYTES;
         const char* as = c.tile + (long long)c.h * BLOCK_BYTES;
         lds_dma16(as + offA0, st + wave * 1024);
         lds_dma16(as + offA1, st + (wave + 8) * 1024);
     }
     __device__ __forceinline__ void issue_b(int h, int stage, int piece) const {
-        char* st = smem + stage * STAGE_BYTES + OPER_BYTES;
+        char* st = smem + OFF_B + stage * OPER_BYTES;
         const char* bs = qbase + h * HALF_BYTES;
         if (piece == 0) lds_dma16(bs + offB0, st + wave * 1024);
         else lds_dma16(bs + offB1, st + (wave + 8) * 1024);
@@ -206,13 +211,16 @@ __device__ __forceinline__ void tile_thresholds(const int (&thr)[4], int s, int 
     }
 }
 
-__device__ __forceinline__ void read_operands(const S8& P, AOps& a, BOps& b, int j) {
-    const char* st = P.smem + (j & 3) * STAGE_BYTES;
+// operands of half-step j: rows from stage sa of their ring, queries from stage j & 3 of theirs
+__device__ __forceinline__ void read_operands(const S8& P, AOps& a, BOps& b, int j, int sa) {
+    const char* sta = P.smem + sa * OPER_BYTES;
+    const char* stb = P.smem + OFF_B + (j & 3) * OPER_BYTES;
 #pragma unroll
-    for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const i32x4*>(st + P.rdA + fm * 2048);
+    for (int fm = 0; fm < 8; ++fm) a[fm] = *reinterpret_cast<const i32x4*>(sta + P.rdA + fm * 2048);
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const i32x4*>(st + OPER_BYTES + P.rdB + fn * 2048);
+    for (int fn = 0; fn < 4; ++fn) b[fn] = *reinterpret_cast<const i32x4*>(stb + P.rdB + fn * 2048);
 }
+__device__ __forceinline__ void read_operands(const S8& P, AOps& a, BOps& b, int j) { read_operands(P, a, b, j, j & 3); }
 
 // MEMORY phase of half-step j (= P.rd): DMA of half-step j + 3 into the stage half-step j - 1 used, operand reads of
 // half-step j, counted wait that retires this wave's pieces of half-step j + 1 (scan_pp.hip: mem_lean / mem_phase).
@@ -242,62 +250,48 @@ __device__ __forceinline__ uint64_t make_key_i32(int score, uint32_t row) {
     return ((uint64_t)((uint32_t)score ^ 0x80000000u) << 32) | (uint64_t)(0xFFFFFFFFu - row);
 }
 
-// accumulator t (fragment t >> 2, element t & 3) of column group J, t uniform (scan_common.h: pick_acc)
-template <int J>
-__device__ __forceinline__ int pick_acc_i32(const i32x4 (&acc)[8][4], int t) {
-    int v = 0;
-#define SQE_PICK(n) \
-    case n: asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(acc[(n) >> 2][J][(n) & 3])); break;
-#define SQE_PICK4(n) SQE_PICK(n) SQE_PICK((n) + 1) SQE_PICK((n) + 2) SQE_PICK((n) + 3)
-    switch (t) {
-        SQE_PICK4(0) SQE_PICK4(4) SQE_PICK4(8) SQE_PICK4(12) SQE_PICK4(16) SQE_PICK4(20) SQE_PICK4(24) SQE_PICK4(28)
-        default: break;
-    }
-#undef SQE_PICK4
-#undef SQE_PICK
-    return v;
-}
-
-// append path of one column group of a finished tile (scan_common.h: filter_group, integer scores, no compaction)
+// Append path of one column group of a finished tile (integer scores, no compaction).  The exact predicate acc * s >= thr
+// (|acc| < 2^23, s < 2^16, product < 2^31: quant.hip) is applied fragment by fragment: s >= 1, so the largest of a fragment's four
+// accumulators passes iff any of them does -- one v_max3 + v_max, one multiply and one compare per fragment, and the four values are
+// looked at only where a lane's fragment holds a survivor (a wave-uniform branch; ~13 survivors per 256 x 256 tile at 10 M rows).
+// r03 built a 32-bit mask per lane first (32 x multiply, compare, add-with-carry: ~100 VALU instructions per flagged group) and walked
+// its set bits through a 32-way switch: at the key density of a 1.25 M-row shard (8 x the survivors per tile) that was a quarter of
+// the scan (profiles/r04_search/i8_tile_stamps_1p25m.txt: 34.7 k cycles per tile against 26.5 k at 10 M rows).
 template <int J>
 __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t row_base, int64_t n_rows, bool partial, int qcol, bool live,
-                                              int thr, int scale, int* cnt, uint64_t* cand_base, uint64_t* ovf_base, int* ovf_cnt) {
-    unsigned m = 0;
-    // the exact predicate acc * s >= thr (|acc| < 2^23, s < 2^16, product < 2^31: quant.hip)
-#pragma unroll
-    for (int t = 31; t >= 0; --t) {
-        const int v = __mul24(acc[t >> 2][J][t & 3], scale);
-        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(v), "v"(thr) : "vcc");
-    }
-    if (partial) {                                  // last tile of the index: rows past the end are not rows
-        const int left = (int)min((int64_t)SCAN_BM, max((int64_t)0, n_rows - row_base));
-        unsigned valid = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = min(4, max(0, left - i * 16));
-            valid |= ((1u << n) - 1u) << (i * 4);
-        }
-        m &= valid;
-    }
-    if (!live) m = 0;
-    unsigned todo = wave_or_u32(m);
-    if (todo == 0) return;
-    const int mine = __popc(m);
-    int slot = 0;
-    if (mine) slot = atomicAdd(&cnt[qcol], mine);
+                                              int thr, int scale, int* cnt, uint64_t* cand_base, uint64_t* ovf_base, int* ovf_cnt, int& nst,
+                                              bool no_store = false) {
+    // nst: wave-uniform count of the key-store instructions this wave has issued for the tile (never more than it did issue; < 0: an
+    // entry went to the pool -- its atomic made the compiler drain the queue -- and the count is not used)
     uint64_t* list = cand_base + (size_t)qcol * CAND_CAP;
-    while (todo) {
-        const int t = __builtin_ctz(todo);          // uniform
-        todo &= todo - 1;
-        const int sc = __mul24(pick_acc_i32<J>(acc, t), scale);
-        if (m & (1u << t)) {
-            const int64_t row = row_base + (t >> 2) * 16 + (t & 3);
-            if (slot < CAND_CAP) list[slot] = make_key_i32(sc, (uint32_t)row);
-            else {                                  // the list is full: the query's pool (kernels.h: I8_OVF_CAP)
-                const int o = atomicAdd(&ovf_cnt[qcol], 1);
-                if (o < I8_OVF_CAP) ovf_base[(size_t)qcol * I8_OVF_CAP + o] = make_key_i32(sc, (uint32_t)row);
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+        const i32x4 v = acc[fm][J];
+        const int m4 = max(max(max(v[0], v[1]), v[2]), v[3]);
+        const bool hit = live && __mul24(m4, scale) >= thr;
+        if (__any(hit)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sc = __mul24(v[e], scale);
+                const int64_t row = row_base + fm * 16 + e;
+                const bool ok = hit && sc >= thr && (!partial || row < n_rows);   // (last tile of the index: rows past the end are not rows)
+                if (!__any(ok)) continue;
+                int slot = 0;
+                if (ok) slot = atomicAdd(&cnt[qcol], 1);
+                if (no_store) continue;                     // (knobs build, SQE_I8_DBG = 32, timing only: what the key stores cost)
+                const bool in_list = ok && slot < CAND_CAP;
+                if (__any(in_list)) {
+                    if (in_list) list[slot] = make_key_i32(sc, (uint32_t)row);
+                    ++nst;
+                }
+                if (__any(ok && !in_list)) {                // the list is full: the query's pool (kernels.h: I8_OVF_CAP)
+                    nst = -(1 << 20);
+                    if (ok && !in_list) {
+                        const int o = atomicAdd(&ovf_cnt[qcol], 1);
+                        if (o < I8_OVF_CAP) ovf_base[(size_t)qcol * I8_OVF_CAP + o] = make_key_i32(sc, (uint32_t)row);
+                    }
+                }
             }
-            ++slot;
         }
     }
 }
@@ -376,10 +370,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
 
     // ---- prologue: half-steps 0, 1, 2 (the launcher admits dim >= 256 only: HS >= 4, so J >= 4 whenever J > 0, and the
     // row scales of tile e + 1 -- fetched three half-steps ahead -- never land in the buffer tile e is still using)
+    constexpr bool DEEP = (I8V & 64) != 0;
+    int dmb_h = 0;                              // DEEP: K slice of the next QUERY pieces (half-step j + 3); P.dm is the row cursor (j + 4)
+    int ia = 0, ra = 0;                         // DEEP: row-ring stage of the next issue / the next read (half-step mod 5)
     if (P.J > 0) {
         for (int s = 0; s < 3 && s < P.J; ++s) {
             P.issue(P.dm, s, true);
             P.advance(P.dm);
+        }
+        if (DEEP) {
+            dmb_h = 3 % P.HS;
+            ia = 3;
+            if (3 < P.J) {                      // rows of half-step 3 as well (the launcher admits HS >= 4: h = 3, no scale piece)
+                P.issue_a(P.dm, 3);
+                P.advance(P.dm);
+                ia = 4;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's pieces (inline asm: the compiler does not wait for them)
@@ -405,10 +411,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         // and no barrier of their own: a wave with survivors simply enters its next phase late.  Measured against the common
         // phase behind a barrier that the bf16 kernel needs for its compaction (profiles/r03_search/ab_append_barrier.log):
         // batch 256 -3 %, 768 -1.2 %, 512 and 1024 within +-0.4 %.
-        auto tile_end = [&](int e) {
+#ifdef SQE_DEBUG_KNOBS
+        const bool dbg_no_store = ((p.dbg >> 3) & 32) != 0;      // SQE_I8_DBG = 32 (timing only): keys are counted, not written
+#else
+        constexpr bool dbg_no_store = false;
+#endif
+        auto tile_end = [&](int e) -> int {
+            int nst = 0;
+#ifdef SQE_DEBUG_KNOBS
+            // where a launch's time goes along the chunk: two clocks at tiles 0, 1, 2, 4, 8, ... and at the last one (api.hip prints
+            // microseconds and core MHz per tile for each interval)
+            if (p.stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && ((e & (e - 1)) == 0 || e == P.nt - 1)) {
+                const int slot = e == P.nt - 1 ? 31 : (e == 0 ? 0 : 1 + (31 - __builtin_clz(e)));
+                unsigned long long* o = p.stamps + (blockIdx.x ? 128 : 0) + slot * 3;
+                o[0] = (unsigned long long)e + 1; o[1] = wall_clock64(); o[2] = clock64();
+            }
+#endif
             if (sync_appends) {
                 const bool any = __builtin_amdgcn_readfirstlane(*any_cols) != 0;
-                if (!any) return;
+                if (!any) return 0;
             }
             if (cols) {
                 const int fl = fresh_lane();
@@ -416,16 +437,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 const int64_t row_base = tile_row0 + P.wm * 128 + (fl >> 4) * 4;
                 const bool partial = tile_row0 + SCAN_BM > p.n_rows;
                 const int qc0 = P.wn * 64 + (fl & 15);
-                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
-                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
-                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
-                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base, ovf_base, ovf_cnt);
+                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
+                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
+                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
+                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (sync_appends) {
                 I8_BARRIER();
                 if (tid == 0) *any_cols = 0;       // read again a whole tile later
             }
+            return __builtin_amdgcn_readfirstlane(nst);
         };
 #ifndef SQE_I8_TWO_BARRIERS
         // ONE barrier per half-step.  Period T_j is what lies between barrier B_{j-1} and barrier B_j:
@@ -442,18 +464,65 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         // retire in issue order, so wave 0's scale piece and a wave's appended keys -- extra entries of the queue, older than
         // the four pieces of j + 3 or among them -- only make a wait retire more.
         auto issue_next = [&](int jj) {
+            if (DEEP) {
+                // queries of jj + 3 FIRST, then the rows of jj + 4 (the wait below leaves the rows of jj + 3 in flight: they must be
+                // younger than the queries of jj + 2, which it retires)
+                if (jj + 3 < P.J) {
+                    P.issue_b(dmb_h, (jj + 3) & 3, 0);
+                    P.issue_b(dmb_h, (jj + 3) & 3, 1);
+                    dmb_h = dmb_h + 1 == P.HS ? 0 : dmb_h + 1;
+                }
+                if (jj + 4 < P.J) {
+                    if (P.wave == 0 && P.dm.h == 0)
+                        lds_dma16(P.scales_src + (long long)P.dm.e * P.scales_stride + P.lane * 16, P.smem + OFF_SCALES + (P.dm.e & 1) * 1024);
+                    P.issue_a(P.dm, ia);
+                    P.advance(P.dm);
+                    ia = ia + 1 == NSTA ? 0 : ia + 1;
+                }
+                return;
+            }
             if (jj + 3 < P.J) {
                 P.issue(P.dm, (jj + 3) & 3, true);
                 P.advance(P.dm);
             }
         };
         // at the end of T_jj: this wave's pieces of jj + 2 (and everything older); the pieces of jj + 3 stay in flight
+        // (DEEP: its queue ends ... Q(jj+2) | A(jj+3) x 2 | Q(jj+3) x 2 | A(jj+4) x 2: six entries stay)
         auto wait_pieces = [&](int jj) {
+            if (DEEP) {
+                if (jj + 4 < P.J) I8_WAIT(0x0F76);           // vmcnt(6)
+                else if (jj + 3 < P.J) I8_WAIT(0x0F74);      // vmcnt(4): A(jj+3), Q(jj+3)
+                else I8_WAIT(0x0F70);
+                return;
+            }
             if (jj + 3 < P.J) I8_WAIT(0x0F74);               // vmcnt(4)
             else I8_WAIT(0x0F70);                            // vmcnt(0): nothing was issued in this period
         };
+        // I8V & 128: the appends of a finished tile leave BEHIND the first period's pieces, as the youngest entries of the queue, and that
+        // period's wait lets them stay outstanding (vmcnt(4 + stores)): a wait that has to retire them (operations retire in issue
+        // order) stalls for a store's round trip, once per tile and wave with a survivor.  They are retired a period later, as older
+        // entries of the next wait.  The count never exceeds the stores issued (collect_group), so the pieces of j + 2 are always covered.
+        auto wait_pieces_young = [&](int jj, int nst) {
+            if (DEEP || nst <= 0 || jj + 3 >= P.J) { wait_pieces(jj); return; }
+            switch (nst) {
+                case 1: I8_WAIT(0x0F75); break;
+                case 2: I8_WAIT(0x0F76); break;
+                case 3: I8_WAIT(0x0F77); break;
+                case 4: I8_WAIT(0x0F78); break;
+                case 5: I8_WAIT(0x0F79); break;
+                case 6: I8_WAIT(0x0F7A); break;
+                case 7: I8_WAIT(0x0F7B); break;
+                default: I8_WAIT(0x0F7C); break;             // 8 or more stores: vmcnt(12)
+            }
+        };
+        // every wave reads the half-steps in order, once each: ra is the row stage of its next read
+        auto read_next = [&](int x) {
+            read_operands(P, a, b, x, DEEP ? ra : (x & 3));
+            if (DEEP) ra = ra + 1 == NSTA ? 0 : ra + 1;
+        };
 #ifdef SQE_DEBUG_KNOBS
-        // SQE_I8_DBG (knobs build, run-time A/B): 4 NO raised priority while computing, 16 appends before the barrier
+        // SQE_I8_DBG (knobs build, run-time A/B): 4 NO raised priority while computing, 16 appends before the barrier, 32 no key stores
+        // (timing only: keys are counted, not written)
         const int xdbg = p.dbg >> 3;
 #define I8_PRIO(n) do { if (!(xdbg & 4)) __builtin_amdgcn_s_setprio(n); } while (0)
 #else
@@ -473,32 +542,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         };
         auto g0_tail = [&](int jj) {
             if (I8V & 2) {
-                if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
+                if (jj + 1 < P.J) read_next(jj + 1);
                 issue_next(jj);
                 wait_pieces(jj);
                 return;
             }
             if (I8V & 1) issue_next(jj);
             wait_pieces(jj);
-            if (jj + 1 < P.J) read_operands(P, a, b, jj + 1);
+            if (jj + 1 < P.J) read_next(jj + 1);
         };
         auto g1_head = [&](int jj) {
             if (I8V & 8) {
-                read_operands(P, a, b, jj);
+                read_next(jj);
                 issue_next(jj);
                 return;
             }
             issue_next(jj);
-            read_operands(P, a, b, jj);
+            read_next(jj);
         };
+        constexpr bool YOUNG = (I8V & 128) != 0;
+        int nst_prev = 0;                                    // YOUNG: key stores of the tile finished before this period
         if (group == 0) {
-            read_operands(P, a, b, 0);                       // (the prologue's pieces: retired by every wave before __syncthreads)
+            read_next(0);                                    // (the prologue's pieces: retired by every wave before __syncthreads)
             for (int e = 0; e < P.nt; ++e) {
-                g0_head(j);
-                I8_PRIO(2);
-                cmp_phase<true>(acc, a, b);
-                I8_PRIO(0);
-                g0_tail(j);
+                if (YOUNG) {
+                    // first period of a tile: pieces first (as G1 does), then the finished tile's appends, compute, wait, reads
+                    issue_next(j);
+                    nst_prev = e > 0 ? tile_end(e - 1) : 0;
+                    I8_PRIO(2);
+                    cmp_phase<true>(acc, a, b);
+                    I8_PRIO(0);
+                    wait_pieces_young(j, nst_prev);
+                    if (j + 1 < P.J) read_next(j + 1);
+                } else {
+                    g0_head(j);
+                    I8_PRIO(2);
+                    cmp_phase<true>(acc, a, b);
+                    I8_PRIO(0);
+                    g0_tail(j);
+                }
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
@@ -518,15 +600,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                if (!(xdbg & 16)) tile_end(e);               // (the accumulators are the finished tile's until the next compute part)
+                if (!(xdbg & 16) && (!YOUNG || e + 1 == P.nt)) tile_end(e);   // (the accumulators are the finished tile's until the next compute part)
             }
         } else {
             for (int e = 0; e < P.nt; ++e) {
-                g1_head(j);
+                if (YOUNG) {
+                    issue_next(j);
+                    nst_prev = e > 0 ? tile_end(e - 1) : 0;
+                    read_next(j);
+                } else {
+                    g1_head(j);
+                }
                 I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
                 I8_PRIO(0);
-                wait_pieces(j);
+                if (YOUNG) wait_pieces_young(j, nst_prev);
+                else wait_pieces(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
@@ -546,7 +635,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                if (!(xdbg & 16)) tile_end(e);
+                if (!(xdbg & 16) && (!YOUNG || e + 1 == P.nt)) tile_end(e);
             }
         }
 #undef I8_PRIO
@@ -972,7 +1061,7 @@ int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
     I8KernelArgs k;
     k.db8 = a.db8; k.tile_stride = a.tile_stride; k.sxi = a.sxi; k.q8 = a.q8; k.q_pitch = a.q_pitch; k.thr_int = a.thr_int;
     k.n_rows = a.n_rows; k.K = a.K; k.B = a.B; k.b_pad = a.b_pad; k.n_tiles = a.n_tiles; k.n_chunks = a.n_chunks; k.qblocks = a.qblocks;
-    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.ovf = a.ovf; k.ovf_cnt = a.ovf_cnt;
+    k.cand = a.cand; k.cand_cnt = a.cand_cnt; k.ovf = a.ovf; k.ovf_cnt = a.ovf_cnt; k.stamps = a.stamps;
     if (!a.ovf || !a.ovf_cnt) return fail(SQE_ERR_INVALID, "int8 scan: no overflow pool");
     {
         static const int force = [] { const char* e = knob_env("SQE_I8_SYNC"); return e ? (e[0] == '0' ? 1 : 2) : 0; }();   // knobs build only
