@@ -121,7 +121,8 @@ __global__ void ivf_scatter_kernel(const int* __restrict__ assign, int64_t n, co
 // The GEMM scores come from bf16 operands: the best nprobe + 8 by those scores are re-scored in fp32 (raw query
 // row against the normalised fp32 centroid; dividing by the query norm does not change the order) and the
 // best nprobe of them returned, so the list order is the exact fp32 one.
-__global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __restrict__ scores, int nlist, int nprobe,
+constexpr int PSEL_THREADS = 1024;      // (r04; 256 before: the re-score of the nprobe + 8 best centroids is a chain of row fetches per wave)
+__global__ __launch_bounds__(PSEL_THREADS) void ivf_probe_select_kernel(const float* __restrict__ scores, int nlist, int nprobe,
                                                                const float* __restrict__ rows, const float* __restrict__ cent, int dim,
                                                                int64_t* __restrict__ probes, float* __restrict__ probes_cos) {
     extern __shared__ __attribute__((aligned(16))) float ssc[];      // [nlist]
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
     __shared__ int scratch[4];
     __shared__ uint64_t top[MAX_KP];
     const int q = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < nlist; i += 256) ssc[i] = scores[(size_t)q * nlist + i];
+    for (int i = tid; i < nlist; i += PSEL_THREADS) ssc[i] = scores[(size_t)q * nlist + i];
     __syncthreads();
     auto key_of = [&](int i) { return make_key(ssc[i] + 0.0f, (uint32_t)i); };
     const int nsel = min(min(nprobe + 8, MAX_KP), nlist);      // candidates kept for the fp32 re-score
@@ -137,10 +138,10 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
     int remaining = nsel;
     const bool all = nlist <= nsel;
     for (int byte = 7; byte >= 0 && !all; --byte) {
-        hist[tid] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = byte * 8;
-        for (int i = tid; i < nlist; i += 256) {
+        for (int i = tid; i < nlist; i += PSEL_THREADS) {
             const uint64_t key = key_of(i);
             if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
         }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
     const uint64_t T = all ? 0ull : prefix;
     if (tid == 0) scratch[2] = 0;
     __syncthreads();
-    for (int i = tid; i < nlist; i += 256) {
+    for (int i = tid; i < nlist; i += PSEL_THREADS) {
         const uint64_t key = key_of(i);
         if (key >= T) {
             const int slot = atomicAdd(&scratch[2], 1);
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
             qq = fmaf(b.x, b.x, qq); qq = fmaf(b.y, b.y, qq); qq = fmaf(b.z, b.z, qq); qq = fmaf(b.w, b.w, qq);
         }
         const float inv = 1.0f / (sqrtf(wave_sum(qq)) + 1e-9f);
-        for (int e = wave; e < m; e += 4) {
+        for (int e = wave; e < m; e += PSEL_THREADS / 64) {
             const uint32_t id = key_row(top[e]);
             const float4* cv = reinterpret_cast<const float4*>(cent + (size_t)id * dim);
             float s = 0.f;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
     }
     __syncthreads();
     const int mk = min(m, nprobe);
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += PSEL_THREADS) {
         const uint64_t ki = top[i];
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += top[j] > ki ? 1 : 0;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void ivf_probe_select_kernel(const float* __re
             probes_cos[(size_t)q * nprobe + rank] = key_score(ki);
         }
     }
-    for (int i = mk + tid; i < nprobe; i += 256) {
+    for (int i = mk + tid; i < nprobe; i += PSEL_THREADS) {
         probes[(size_t)q * nprobe + i] = -1;
         probes_cos[(size_t)q * nprobe + i] = -INFINITY;
     }
@@ -827,7 +828,10 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
 
 // per query: the kp best scan scores over the strips of its probed lists, re-scored in fp32 against the
 // master, then the top-k by (fp32 cosine desc, row id asc)
-__global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
+// 1,024 threads per query (r04; 256 before): the strip passes and the re-score are chains of dependent loads per wave -- one query
+// alone took 83 us here, of a 196 us search (profiles/r04_configs/ivf_stream_ablation.log) -- sixteen waves shorten every chain fourfold.
+constexpr int SEL_THREADS = 1024, SEL_WAVES = SEL_THREADS / 64;
+__global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
                                                          const int* __restrict__ order, const float* __restrict__ pair_scores,
                                                          int nprobe, int max_len, int k, int kp, int64_t id_base,
                                                          const float* __restrict__ master, const float* __restrict__ qn, int K,
@@ -846,7 +850,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
     __shared__ int s_total;
     if (tid == 0) s_total = 0;
     __syncthreads();
-    for (int p = tid; p < nprobe; p += 256) {
+    for (int p = tid; p < nprobe; p += SEL_THREADS) {
         const int64_t L = probes[(size_t)q * nprobe + p];
         const int64_t off = L >= 0 ? offsets[L] : 0;
         const int len = L >= 0 ? (int)(offsets[L + 1] - off) : 0;
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
     }
     __syncthreads();
     const int total = s_total;                       // total number of probed rows
-    const int wave4 = tid >> 6, lane64 = tid & 63;
+    const int wave4 = tid >> 6, lane64 = tid & 63;          // (wave4: one of SEL_WAVES)
     // ---- fast path: a threshold from a strided sample, ONE pass over the strips that collects every key
     // at or above it, exact top-kp among the few collected.  (The general path below walks the strips
     // eight times; it remains the fallback when the sample misjudges the tail.)  One wave per strip in both passes.
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         const int stride = (total + 8191) / 8192;
         if (tid == 0) { scratch[0] = 0; scratch[2] = 0; }
         __syncthreads();
-        for (int p = wave4; p < nprobe; p += 4) {
+        for (int p = wave4; p < nprobe; p += SEL_WAVES) {
             const int len = s_len[p];
             const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
             for (int i = lane64 * stride + (p % stride); i < len; i += 64 * stride) {
@@ -888,10 +892,10 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
             uint32_t pre = 0;
             int rem = want;
             for (int byte = 3; byte >= 0; --byte) {
-                hist[tid] = 0;
+                if (tid < 256) hist[tid] = 0;
                 __syncthreads();
                 const int shift = byte * 8;
-                for (int i = tid; i < ns; i += 256) {
+                for (int i = tid; i < ns; i += SEL_THREADS) {
                     const uint32_t v32 = sample[i];
                     if (byte == 3 || (v32 >> (shift + 8)) == (pre >> (shift + 8))) atomicAdd(&hist[(v32 >> shift) & 0xff], 1);
                 }
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
             }
             thr = pre;
         }
-        for (int p = wave4; p < nprobe; p += 4) {
+        for (int p = wave4; p < nprobe; p += SEL_WAVES) {
             const int len = s_len[p];
             const int64_t off = s_off[p];
             const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;   // (16-byte aligned: max_len is a multiple of 4)
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         const int nc = scratch[2];
         __syncthreads();
         if (nc >= kp && nc <= COLLECT_CAP) {
-            for (int i = tid; i < nc; i += 256) {
+            for (int i = tid; i < nc; i += SEL_THREADS) {
                 const uint64_t ki = coll[i];
                 int rank = 0;
                 for (int j = 0; j < nc; ++j) rank += coll[j] > ki ? 1 : 0;
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
     int remaining = kp;
     const bool all = total <= kp;
     for (int byte = 7; byte >= 0 && !all && !done; --byte) {
-        hist[tid] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = byte * 8;
         for (int p = 0; p < nprobe; ++p) {
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
             if (L < 0) continue;
             const int64_t off = offsets[L];
             const int len = (int)(offsets[L + 1] - off);
-            for (int i = tid; i < len; i += 256) {
+            for (int i = tid; i < len; i += SEL_THREADS) {
                 const uint64_t key = key_at(p, i, off);
                 const float sc = key_score(key);
                 if (sc != sc) continue;                                   // NaN rows never rank
@@ -979,7 +983,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         if (L < 0) continue;
         const int64_t off = offsets[L];
         const int len = (int)(offsets[L + 1] - off);
-        for (int i = tid; i < len; i += 256) {
+        for (int i = tid; i < len; i += SEL_THREADS) {
             const uint64_t key = key_at(p, i, off);
             const float sc = key_score(key);
             if (sc == sc && key >= T) {
@@ -995,7 +999,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
         const int lane = tid & 63, wave = tid >> 6;
         const float4* qv = reinterpret_cast<const float4*>(qn + (size_t)q * K);
         const int nvec = K >> 2;
-        for (int e = wave; e < m; e += 4) {
+        for (int e = wave; e < m; e += SEL_WAVES) {
             const uint32_t row = key_row(top[e]);
             const float4* rv = reinterpret_cast<const float4*>(master + (size_t)row * K);
             float s = 0.f;
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
     }
     __syncthreads();
     const int mk = min(m, k);
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += SEL_THREADS) {
         const uint64_t ki = top[i];
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += top[j] > ki ? 1 : 0;
@@ -1018,7 +1022,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const int64_t* __restri
             id_out[(size_t)q * k + rank] = (int64_t)key_row(ki) + id_base;
         }
     }
-    for (int i = mk + tid; i < k; i += 256) {
+    for (int i = mk + tid; i < k; i += SEL_THREADS) {
         cos_out[(size_t)q * k + i] = -INFINITY;
         id_out[(size_t)q * k + i] = -1;
     }
@@ -1079,7 +1083,7 @@ static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev,
         SQE_TRY(launch_normalize_rows(rows_dev + (size_t)off * dim, m, dim, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
         SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, m, t_pad,
                                    ctx->cu_count, s));
-        hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(m), dim3(256), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, kk,
+        hipLaunchKernelGGL(ivf_probe_select_kernel, dim3(m), dim3(PSEL_THREADS), (size_t)nlist * 4, s, st->cscores.as<float>(), nlist, kk,
                            rows_dev + (size_t)off * dim, st->coarse->master, dim, ids_out + off * kk, cos_out + off * kk);
         SQE_HIP(hipGetLastError());
     }
@@ -1362,7 +1366,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                            pitch, st->order.as<int>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe,
                            dim, max_len, st->pair_scores.as<float>());
     }
-    hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
+    hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                        st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, base->id_base,
                        base->master, st->qn.as<float>(), dim, cos_out, id_out);
     SQE_HIP(hipGetLastError());

@@ -119,6 +119,8 @@ struct I8ScanArgs {
 // the query's pool (one global atomic per key, rare) and the query stays certifiable.
 constexpr int I8_OVF_CAP = 4096;
 int launch_scan_i8(const I8ScanArgs& args, hipStream_t stream);
+// the same scan built with a five-stage row ring (scan_i8_deep.hip): one 256-query block per chunk, where every tile comes from HBM
+int launch_scan_i8_deep(const I8ScanArgs& args, hipStream_t stream);
 // Threshold pass in int8: every step-th (whole) tile against query blocks of 256; out[chunk][query][16] = the two best
 // (scaled score, row) of each of the 8 row lanes (scan_i8.hip: sample_i8_pp_kernel).  b_pad is a multiple of 256.
 struct I8SampleArgs {

@@ -259,10 +259,7 @@ __device__ __forceinline__ uint64_t make_key_i32(int score, uint32_t row) {
 // the scan (profiles/r04_search/i8_tile_stamps_1p25m.txt: 34.7 k cycles per tile against 26.5 k at 10 M rows).
 template <int J>
 __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t row_base, int64_t n_rows, bool partial, int qcol, bool live,
-                                              int thr, int scale, int* cnt, uint64_t* cand_base, uint64_t* ovf_base, int* ovf_cnt, int& nst,
-                                              bool no_store = false) {
-    // nst: wave-uniform count of the key-store instructions this wave has issued for the tile (never more than it did issue; < 0: an
-    // entry went to the pool -- its atomic made the compiler drain the queue -- and the count is not used)
+                                              int thr, int scale, int* cnt, uint64_t* cand_base, uint64_t* ovf_base, int* ovf_cnt, bool no_store = false) {
     uint64_t* list = cand_base + (size_t)qcol * CAND_CAP;
 #pragma unroll
     for (int fm = 0; fm < 8; ++fm) {
@@ -276,17 +273,12 @@ __device__ __forceinline__ void collect_group(const i32x4 (&acc)[8][4], int64_t 
                 const int64_t row = row_base + fm * 16 + e;
                 const bool ok = hit && sc >= thr && (!partial || row < n_rows);   // (last tile of the index: rows past the end are not rows)
                 if (!__any(ok)) continue;
-                int slot = 0;
-                if (ok) slot = atomicAdd(&cnt[qcol], 1);
-                if (no_store) continue;                     // (knobs build, SQE_I8_DBG = 32, timing only: what the key stores cost)
-                const bool in_list = ok && slot < CAND_CAP;
-                if (__any(in_list)) {
-                    if (in_list) list[slot] = make_key_i32(sc, (uint32_t)row);
-                    ++nst;
-                }
-                if (__any(ok && !in_list)) {                // the list is full: the query's pool (kernels.h: I8_OVF_CAP)
-                    nst = -(1 << 20);
-                    if (ok && !in_list) {
+                if (no_store) continue;                     // (knobs build, SQE_I8_DBG = 32, timing only: survivors found, nothing appended --
+                                                            //  every query then takes the bf16 pass; read the kernel's time under rocprofv3)
+                if (ok) {
+                    const int slot = atomicAdd(&cnt[qcol], 1);
+                    if (slot < CAND_CAP) list[slot] = make_key_i32(sc, (uint32_t)row);
+                    else {                                  // the list is full: the query's pool (kernels.h: I8_OVF_CAP)
                         const int o = atomicAdd(&ovf_cnt[qcol], 1);
                         if (o < I8_OVF_CAP) ovf_base[(size_t)qcol * I8_OVF_CAP + o] = make_key_i32(sc, (uint32_t)row);
                     }
@@ -412,12 +404,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         // phase behind a barrier that the bf16 kernel needs for its compaction (profiles/r03_search/ab_append_barrier.log):
         // batch 256 -3 %, 768 -1.2 %, 512 and 1024 within +-0.4 %.
 #ifdef SQE_DEBUG_KNOBS
-        const bool dbg_no_store = ((p.dbg >> 3) & 32) != 0;      // SQE_I8_DBG = 32 (timing only): keys are counted, not written
+        const bool dbg_no_store = ((p.dbg >> 3) & 32) != 0;      // SQE_I8_DBG = 32 (timing only): survivors found, not appended
 #else
         constexpr bool dbg_no_store = false;
 #endif
-        auto tile_end = [&](int e) -> int {
-            int nst = 0;
+        auto tile_end = [&](int e) {
 #ifdef SQE_DEBUG_KNOBS
             // where a launch's time goes along the chunk: two clocks at tiles 0, 1, 2, 4, 8, ... and at the last one (api.hip prints
             // microseconds and core MHz per tile for each interval)
@@ -429,7 +420,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
 #endif
             if (sync_appends) {
                 const bool any = __builtin_amdgcn_readfirstlane(*any_cols) != 0;
-                if (!any) return 0;
+                if (!any) return;
             }
             if (cols) {
                 const int fl = fresh_lane();
@@ -437,17 +428,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 const int64_t row_base = tile_row0 + P.wm * 128 + (fl >> 4) * 4;
                 const bool partial = tile_row0 + SCAN_BM > p.n_rows;
                 const int qc0 = P.wn * 64 + (fl & 15);
-                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
-                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
-                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
-                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, nst, dbg_no_store);
+                if (cols & 1u) collect_group<0>(acc, row_base, p.n_rows, partial, qc0, qc0 < q_live, thr[0], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, dbg_no_store);
+                if (cols & 2u) collect_group<1>(acc, row_base, p.n_rows, partial, qc0 + 16, qc0 + 16 < q_live, thr[1], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, dbg_no_store);
+                if (cols & 4u) collect_group<2>(acc, row_base, p.n_rows, partial, qc0 + 32, qc0 + 32 < q_live, thr[2], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, dbg_no_store);
+                if (cols & 8u) collect_group<3>(acc, row_base, p.n_rows, partial, qc0 + 48, qc0 + 48 < q_live, thr[3], tile_scale, cnt, cand_base, ovf_base, ovf_cnt, dbg_no_store);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (sync_appends) {
                 I8_BARRIER();
                 if (tid == 0) *any_cols = 0;       // read again a whole tile later
             }
-            return __builtin_amdgcn_readfirstlane(nst);
         };
 #ifndef SQE_I8_TWO_BARRIERS
         // ONE barrier per half-step.  Period T_j is what lies between barrier B_{j-1} and barrier B_j:
@@ -498,31 +488,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
             if (jj + 3 < P.J) I8_WAIT(0x0F74);               // vmcnt(4)
             else I8_WAIT(0x0F70);                            // vmcnt(0): nothing was issued in this period
         };
-        // I8V & 128: the appends of a finished tile leave BEHIND the first period's pieces, as the youngest entries of the queue, and that
-        // period's wait lets them stay outstanding (vmcnt(4 + stores)): a wait that has to retire them (operations retire in issue
-        // order) stalls for a store's round trip, once per tile and wave with a survivor.  They are retired a period later, as older
-        // entries of the next wait.  The count never exceeds the stores issued (collect_group), so the pieces of j + 2 are always covered.
-        auto wait_pieces_young = [&](int jj, int nst) {
-            if (DEEP || nst <= 0 || jj + 3 >= P.J) { wait_pieces(jj); return; }
-            switch (nst) {
-                case 1: I8_WAIT(0x0F75); break;
-                case 2: I8_WAIT(0x0F76); break;
-                case 3: I8_WAIT(0x0F77); break;
-                case 4: I8_WAIT(0x0F78); break;
-                case 5: I8_WAIT(0x0F79); break;
-                case 6: I8_WAIT(0x0F7A); break;
-                case 7: I8_WAIT(0x0F7B); break;
-                default: I8_WAIT(0x0F7C); break;             // 8 or more stores: vmcnt(12)
-            }
-        };
         // every wave reads the half-steps in order, once each: ra is the row stage of its next read
         auto read_next = [&](int x) {
             read_operands(P, a, b, x, DEEP ? ra : (x & 3));
             if (DEEP) ra = ra + 1 == NSTA ? 0 : ra + 1;
         };
 #ifdef SQE_DEBUG_KNOBS
-        // SQE_I8_DBG (knobs build, run-time A/B): 4 NO raised priority while computing, 16 appends before the barrier, 32 no key stores
-        // (timing only: keys are counted, not written)
+        // SQE_I8_DBG (knobs build, run-time A/B): 4 NO raised priority while computing, 16 appends before the barrier, 32 survivors are found
+        // but not appended (timing only)
         const int xdbg = p.dbg >> 3;
 #define I8_PRIO(n) do { if (!(xdbg & 4)) __builtin_amdgcn_s_setprio(n); } while (0)
 #else
@@ -534,7 +507,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
         // switches made hipcc spill; the invariant holds in every form): 0 G0 issues its pieces at the HEAD of the period as G1 does
         // (two periods of latency cover, but all eight waves queue at the address unit at once), 1 (shipped) BEHIND its compute
         // part (compute | pieces | vmcnt | reads: the two groups' pieces leave at different times; one period of cover is enough),
-        // 2 as 1 with the reads in front of the pieces, 8 G1 reads before it issues.  Measured at 10 M x 1024
+        // 2 as 1 with the reads in front of the pieces, 8 G1 reads before it issues, 64 a five-stage row ring (scan_i8_deep.hip ships
+        // it for single-block batches).  (r04 also tried the appends as the YOUNGEST entries of the queue, so that the first wait of a
+        // tile need not retire them: no change at 10 M or 1.25 M rows, profiles/r04_search/ab_young_stores.log; not kept.)  Measured at 10 M x 1024
         // (profiles/r04_search/ab_schedule_variants.log), batch 1024 / 256: 0: 9.10-9.16 / 2.62-2.63 ms, 1: 8.44-8.46 / 2.52-2.62,
         // 2: 8.47-8.52 / 2.53, 9: 8.45-8.49 / 2.57-2.64, 10: 8.40-8.45 / 2.56-2.57.
         auto g0_head = [&](int jj) {
@@ -560,27 +535,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
             issue_next(jj);
             read_next(jj);
         };
-        constexpr bool YOUNG = (I8V & 128) != 0;
-        int nst_prev = 0;                                    // YOUNG: key stores of the tile finished before this period
         if (group == 0) {
             read_next(0);                                    // (the prologue's pieces: retired by every wave before __syncthreads)
             for (int e = 0; e < P.nt; ++e) {
-                if (YOUNG) {
-                    // first period of a tile: pieces first (as G1 does), then the finished tile's appends, compute, wait, reads
-                    issue_next(j);
-                    nst_prev = e > 0 ? tile_end(e - 1) : 0;
-                    I8_PRIO(2);
-                    cmp_phase<true>(acc, a, b);
-                    I8_PRIO(0);
-                    wait_pieces_young(j, nst_prev);
-                    if (j + 1 < P.J) read_next(j + 1);
-                } else {
-                    g0_head(j);
-                    I8_PRIO(2);
-                    cmp_phase<true>(acc, a, b);
-                    I8_PRIO(0);
-                    g0_tail(j);
-                }
+                g0_head(j);
+                I8_PRIO(2);
+                cmp_phase<true>(acc, a, b);
+                I8_PRIO(0);
+                g0_tail(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
@@ -600,22 +562,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                if (!(xdbg & 16) && (!YOUNG || e + 1 == P.nt)) tile_end(e);   // (the accumulators are the finished tile's until the next compute part)
+                if (!(xdbg & 16)) tile_end(e);               // (the accumulators are the finished tile's until the next compute part)
             }
         } else {
             for (int e = 0; e < P.nt; ++e) {
-                if (YOUNG) {
-                    issue_next(j);
-                    nst_prev = e > 0 ? tile_end(e - 1) : 0;
-                    read_next(j);
-                } else {
-                    g1_head(j);
-                }
+                g1_head(j);
                 I8_PRIO(2);
                 cmp_phase<true>(acc, a, b);
                 I8_PRIO(0);
-                if (YOUNG) wait_pieces_young(j, nst_prev);
-                else wait_pieces(j);
+                wait_pieces(j);
                 I8_BARRIER();
                 ++j;
                 for (int h = 1; h < HS - 1; ++h) {
@@ -635,7 +590,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_pp_kernel(I8KernelArgs p
                 if (xdbg & 16) tile_end(e);
                 I8_BARRIER();
                 ++j;
-                if (!(xdbg & 16) && (!YOUNG || e + 1 == P.nt)) tile_end(e);
+                if (!(xdbg & 16)) tile_end(e);
             }
         }
 #undef I8_PRIO

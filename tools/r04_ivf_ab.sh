@@ -15,12 +15,26 @@ for t in "$@"; do
   python3 - $out/prof_${t:-shipped} <<'PY' | tee -a $out/ab.log
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)
-mx = collections.defaultdict(int)
-for row in csv.DictReader(open(f[0])):
-    n = row['Kernel_Name']
-    if 'ivf_' in n:
-        mx[n.split('(')[0][:60]] = max(mx[n.split('(')[0][:60]], int(row['End_Timestamp']) - int(row['Start_Timestamp']))
-for n, v in sorted(mx.items(), key=lambda kv: -kv[1]):
-    print(f"   longest dispatch {v / 1e3:9.1f} us  {n}")
+rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r['Start_Timestamp']))
+def short(n):
+    n = n[n.index('sqe::') :] if 'sqe::' in n else n
+    return n.replace('(anonymous namespace)::', '').replace('sqe::', '').split('(')[0][:44]
+dur = collections.defaultdict(list)
+for r in rows:
+    if 'sqe::' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']:
+        dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+for n, v in sorted(dur.items(), key=lambda kv: -max(kv[1])):
+    if n.startswith('ivf_') or 'gemm_ring' in n or 'normalize' in n or 'quantize_rows' in n:
+        print(f"   {n:46s} dispatches {len(v):5d}   longest {max(v):9.1f} us (batch 1024)   shortest {min(v):7.1f} us (batch 1)")
+# the kernels of the LAST batch-1 search of the run (the sweep ends with the flat index: take the last ivf_select whose strip pass was short)
+sel = [i for i, r in enumerate(rows) if 'ivf_select_kernel' in r['Kernel_Name']]
+one = min(sel, key=lambda i: int(rows[i]['End_Timestamp']) - int(rows[i]['Start_Timestamp']))
+j = one
+while j > 0 and 'ivf_select_kernel' not in rows[j - 1]['Kernel_Name'] and one - j < 12: j -= 1
+t0 = int(rows[j]['Start_Timestamp'])
+print("   one query (batch 1), kernel by kernel:")
+for r in rows[j:one + 1]:
+    print(f"      +{(int(r['Start_Timestamp']) - t0) / 1e3:7.1f} us  {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  {short(r['Kernel_Name'])}")
+print(f"      = {(int(rows[one]['End_Timestamp']) - t0) / 1e3:.1f} us from the first kernel's start to the last one's end")
 PY
 done
