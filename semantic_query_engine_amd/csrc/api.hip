@@ -710,7 +710,8 @@ int index_search_impl(sqe_index* idx, const float* q_dev, int B, int k, int npro
                 SQE_HIP(hipMemsetAsync(idx->dbg.p, 0, 8192, s));
                 ia.stamps = idx->dbg.as<unsigned long long>();
             }
-            if (plan.bn == 256 && plan.qblocks == 1) SQE_TRY(launch_scan_i8_deep(ia, s));      // (scan_i8_deep.hip)
+            static const int deep_max = [] { const char* e = knob_env("SQE_I8_DEEP_MAX"); return e ? atoi(e) : 1; }();   // knobs build: A/B of the cut
+            if (plan.bn == 256 && plan.qblocks <= deep_max) SQE_TRY(launch_scan_i8_deep(ia, s));      // (scan_i8_deep.hip)
             else SQE_TRY(launch_scan_i8(ia, s));
             if (want_stamps) {
                 unsigned long long h[256];

@@ -647,7 +647,7 @@ constexpr int ST_Q = 32;                  // queries of a list resident in LDS p
 constexpr int ST_RING = 16;               // 1-KiB row fragments in flight per wave
 constexpr int ST_FR = 4;                  // fragments (16 rows each) of a wave per K slice: 4 waves x 64 rows = a 256-row tile
 constexpr int ST_SL = ST_RING / ST_FR;    // K slices the ring holds
-constexpr int ST_UNIT_TILES = 4;
+constexpr int ST_UNIT_TILES = 5;
 constexpr int ST_THREADS = 256;
 constexpr int ST_PATCH_PITCH = 68;        // floats per query row of a wave's transpose patch: 64 rows + 4 (16-byte rows of different queries on different banks)
 constexpr int ST_PATCH_ROWS = 36;         // query rows of patch per wave: four tiles of <= 8 (padded: 9) queries, one tile of 32
@@ -691,19 +691,39 @@ __device__ __forceinline__ void st_group(i32x4_t (&ring)[ST_RING], i32x4_t (&acc
     }
 }
 
+// COLLECT (r04b): the scores are not written to strips.  A sample pass (this kernel in strip mode over the FIRST tile of every list,
+// ~10 % of the rows) and ivf_threshold_kernel have given every query a threshold that a few hundred of its ~78 k probed rows reach;
+// the pass over the other tiles keeps only the (score, row) keys at or above it: they wait in an LDS buffer of the workgroup and go to
+// the query's list (one global atomic per key) behind the unit's last load.  ivf_select_list_kernel ranks the list.  The 320 MB of
+// strips per batch of 1024 and the pass that re-read them are gone (what is left of them: the sample's 32 MB).
+struct StCollect {
+    const float* thr;          // [B] per-query threshold on the estimated cosine
+    int* cnt;                  // [B] keys appended to a query's list (may exceed list_cap: overflow -> the fallback)
+    uint64_t* list;            // [B, list_cap]
+    int list_cap;
+    const int* order;          // row id of every list position
+};
+constexpr int ST_CBUF = 1024;  // keys a workgroup can hold back per unit and pass (~40 expected)
+template <bool COLLECT>
 __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const int8_t* __restrict__ scan, int64_t tile_stride, const uint32_t* __restrict__ sxi,
                                                                         const int8_t* __restrict__ qb, int qpitch, const uint32_t* __restrict__ sqi, float unit2,
                                                                         const int4* __restrict__ units, const int64_t* __restrict__ tile_off,
                                                                         const int64_t* __restrict__ offsets, const int* __restrict__ lcount,
                                                                         const int* __restrict__ lq, int cap, int nprobe, int K, int max_len,
-                                                                        float* __restrict__ pair_scores) {
+                                                                        float* __restrict__ pair_scores, StCollect col, const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate && *gate == 0) return;                            // (the strip-mode fallback of a collect search: only if some query asked for it)
     const int qrow = K + 128;                                  // LDS pitch of a query row: rows r and r + 1 start 32 banks apart
     float* sscale = reinterpret_cast<float*>(smem + ST_Q * qrow);          // [ST_UNIT_TILES * 256] row scales of the unit
     int* spair = reinterpret_cast<int*>(sscale + ST_UNIT_TILES * LS_ROWS);
     float* sqscale = reinterpret_cast<float*>(spair + ST_Q);
     // per wave: ST_PATCH_ROWS query rows of [64 rows + 4] floats: the transposed scores of finished tiles, waiting for their stores
     float* spatch = sqscale + ST_Q + (threadIdx.x >> 6) * (ST_PATCH_ROWS * ST_PATCH_PITCH);
+    // COLLECT: the patch region holds the workgroup's key buffer instead: [ST_CBUF] keys, [ST_CBUF] query columns, a counter, thresholds
+    uint64_t* cbuf_key = reinterpret_cast<uint64_t*>(sqscale + ST_Q);
+    unsigned char* cbuf_col = reinterpret_cast<unsigned char*>(cbuf_key + ST_CBUF);
+    int* cbuf_n = reinterpret_cast<int*>(cbuf_col + ST_CBUF);
+    float* sthr = reinterpret_cast<float*>(cbuf_n + 4);        // [ST_Q]
     const int4 u = units[blockIdx.x];
     const int L = u.x, ntiles = u.z;
     const int m = min(lcount[L], cap);
@@ -734,11 +754,13 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
             const int pr = lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
             spair[tid] = pr;
             sqscale[tid] = unit2 * (float)sqi[pr / nprobe];
+            if (COLLECT) sthr[tid] = tid < gq ? col.thr[pr / nprobe] : INFINITY;
         }
+        if (COLLECT && tid == 0) *cbuf_n = 0;
         __syncthreads();
         {
             const int cpr = K >> 4;                            // 16-byte chunks per query row
-            for (int c = tid; c < ST_Q * cpr; c += ST_THREADS) {
+            for (int c = tid; c < gq * cpr; c += ST_THREADS) {   // (rows >= gq keep stale bytes: their columns are never stored or compared)
                 const int r = c / cpr, cc = c - r * cpr;
                 const i32x4_t v = *reinterpret_cast<const i32x4_t*>(qb + (size_t)(spair[r] / nprobe) * qpitch + cc * 16);
                 *reinterpret_cast<i32x4_t*>(smem + r * qrow + ((cc ^ ((r >> 1) & 7)) << 4)) = v;
@@ -786,6 +808,47 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
             nslot = 0;
         };
         auto write_tile = [&](int t, bool last) {
+            if (COLLECT) {
+                // keys at or above the query's threshold into the workgroup's buffer (LDS atomics: nothing here enters the vector-memory queue)
+                const int trow = row0 + t * LS_ROWS + wave * (ST_FR * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = j * 16 + (lane & 15);
+                    const float qs = sqscale[c], th = sthr[c];
+#pragma unroll
+                    for (int i = 0; i < ST_FR; ++i) {
+                        const int r = i * 16 + (lane >> 4) * 4;
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(sscale + t * LS_ROWS + wave * (ST_FR * 16) + r);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)acc[i][j][e] * rs[e] * qs;
+                        const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        if (__any(m4 >= th)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (v[e] >= th && trow + r + e < len_all) {
+                                    const int at = atomicAdd(cbuf_n, 1);
+                                    if (at < ST_CBUF) {
+                                        cbuf_key[at] = make_key(v[e], (uint32_t)(trow + r + e));     // (row = position inside the list, for now)
+                                        cbuf_col[at] = (unsigned char)c;
+                                    } else {
+                                        // the buffer is full (a crowd: every row of the unit passes for some query): straight to the list -- the
+                                        // atomic's return drains this wave's ring, once in a long while
+                                        const int q = spair[c] / nprobe;
+                                        const int slot = atomicAdd(col.cnt + q, 1);
+                                        if (slot < col.list_cap)
+                                            col.list[(size_t)q * col.list_cap + slot] = make_key(v[e], (uint32_t)col.order[offsets[L] + trow + r + e]);
+                                    }
+                                }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < ST_FR; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+                return;
+            }
             if (nslot == 0) slot_t0 = t;
             float* patch = spatch + nslot * gq_pad * ST_PATCH_PITCH;
 #pragma unroll
@@ -823,6 +886,102 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
         }
         st_group<false>(ring, acc, bbase + gt * ST_SL * 64, qrow, bcq, bsw, cur, HS, tile_stride, aoff);
         write_tile(t, true);
+        if (COLLECT) {
+            __syncthreads();                                   // every wave's keys are in the buffer; no load is in flight any more
+            const int n = *cbuf_n;
+            const int64_t off = offsets[L];
+            for (int i = tid; i < min(n, ST_CBUF); i += ST_THREADS) {
+                const uint64_t key = cbuf_key[i];
+                const int q = spair[cbuf_col[i]] / nprobe;
+                const int slot = atomicAdd(col.cnt + q, 1);
+                if (slot < col.list_cap) col.list[(size_t)q * col.list_cap + slot] = make_key(key_score(key), (uint32_t)col.order[off + key_row(key)]);
+            }
+        }
+    }
+}
+
+// Threshold of a query for the collect pass, from the sample strips (the first min(256, len) scores of each of its probed lists): the
+// r-th largest sample score, r placed so that ~8 kp rows of the whole probed set are expected at or above it (r = 8 kp x sample
+// fraction, plus three standard deviations of that count and 2), and the sample's own entries at or above it start the query's list.
+// A probed set small enough to fit the list whole gets -inf.  One workgroup of 256 threads per query.
+constexpr int IVF_LIST_CAP = 8192;      // keys of a query's list: a whole cluster of near-ties (2,441 rows in SURVEY 8(d)'s set) must fit
+__global__ __launch_bounds__(256) void ivf_threshold_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
+                                                            const int* __restrict__ order, const float* __restrict__ pair_scores,
+                                                            int nprobe, int max_len, int kp, float* __restrict__ thr_out,
+                                                            int* __restrict__ cnt, uint64_t* __restrict__ list) {
+    __shared__ uint32_t samp[MAX_KP * 32];                   // up to 256 scores of each of up to 32 probed lists... (nprobe <= 32 here)
+    __shared__ int s_len[32], s_pos[33];
+    __shared__ int64_t s_off[32];
+    __shared__ int hist[256];
+    __shared__ int scratch[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { scratch[0] = 0; scratch[2] = 0; }
+    if (tid < nprobe) {
+        const int64_t L = probes[(size_t)q * nprobe + tid];
+        const int64_t off = L >= 0 ? offsets[L] : 0;
+        s_off[tid] = off;
+        s_len[tid] = L >= 0 ? (int)(offsets[L + 1] - off) : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0, total = 0;
+        for (int p = 0; p < nprobe; ++p) { s_pos[p] = pos; pos += min(s_len[p], LS_ROWS); total += s_len[p]; }
+        s_pos[nprobe] = pos;
+        scratch[3] = total;
+    }
+    __syncthreads();
+    const int S = s_pos[nprobe], total = scratch[3];
+    for (int p = 0; p < nprobe; ++p) {
+        const int n = s_pos[p + 1] - s_pos[p];
+        const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
+        for (int i = tid; i < n; i += 256) {
+            const float sc = strip[i];
+            samp[s_pos[p] + i] = sc == sc ? f32_orderable(sc + 0.0f) : 0u;      // (NaN rows never rank)
+        }
+    }
+    __syncthreads();
+    uint32_t thr = 0;                                          // orderable -inf: everything
+    if (total > IVF_LIST_CAP / 4 && S > 0) {
+        const float t = 8.0f * (float)kp * (float)S / (float)total;
+        const int want = min(S, (int)(t + 3.0f * sqrtf(t) + 2.0f));
+        uint32_t pre = 0;
+        int rem = want;
+        for (int byte = 3; byte >= 0; --byte) {
+            hist[tid] = 0;
+            __syncthreads();
+            const int shift = byte * 8;
+            for (int i = tid; i < S; i += 256) {
+                const uint32_t v32 = samp[i];
+                if (byte == 3 || (v32 >> (shift + 8)) == (pre >> (shift + 8))) atomicAdd(&hist[(v32 >> shift) & 0xff], 1);
+            }
+            __syncthreads();
+            {
+                int hb, hr;
+                hist_locate(hist, rem, hb, hr);
+                if (tid == 0) { scratch[1] = hb < 0 ? 0 : hb; scratch[0] = hr; }
+            }
+            __syncthreads();
+            pre |= ((uint32_t)scratch[1] << shift);
+            rem = scratch[0];
+            __syncthreads();
+        }
+        thr = pre;
+    }
+    // the sample's own entries at or above the threshold open the list
+    for (int p = 0; p < nprobe; ++p) {
+        const int n = s_pos[p + 1] - s_pos[p];
+        for (int i = tid; i < n; i += 256) {
+            const uint32_t v32 = samp[s_pos[p] + i];
+            if (v32 != 0u && v32 >= thr) {
+                const int slot = atomicAdd(&scratch[2], 1);
+                if (slot < IVF_LIST_CAP) list[(size_t)q * IVF_LIST_CAP + slot] = make_key(f32_from_orderable(v32), (uint32_t)order[s_off[p] + i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cnt[q] = scratch[2];
+        thr_out[q] = thr == 0u ? -INFINITY : f32_from_orderable(thr);
     }
 }
 
@@ -835,10 +994,11 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
                                                          const int* __restrict__ order, const float* __restrict__ pair_scores,
                                                          int nprobe, int max_len, int k, int kp, int64_t id_base,
                                                          const float* __restrict__ master, const float* __restrict__ qn, int K,
-                                                         float* __restrict__ cos_out, int64_t* __restrict__ id_out) {
+                                                         float* __restrict__ cos_out, int64_t* __restrict__ id_out, const int* __restrict__ gate) {
     __shared__ int hist[256];
     __shared__ int scratch[4];
     __shared__ uint64_t top[MAX_KP];
+    if (gate && *gate == 0) return;                  // (the strip-mode fallback of a collect search: only if some query asked for it)
     const int q = blockIdx.x, tid = threadIdx.x;
     auto key_at = [&](int p, int i, int64_t off) {
         return make_key(pair_scores[((size_t)q * nprobe + p) * max_len + i], (uint32_t)order[off + i]);
@@ -1028,6 +1188,74 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
     }
 }
 
+// Collect mode: the query's list holds every (estimated score, row) at or above its threshold -- a few hundred keys.  The kp best by
+// estimate (rank counting in LDS) are re-scored in fp32 against the master and ranked, as ivf_select_kernel does for the strips.  A
+// list that overflowed, or holds fewer than kp keys although more rows were probed, cannot answer: the query raises the fallback flag
+// and the strip-mode pass (gated launches behind this kernel) answers the whole batch.
+__global__ __launch_bounds__(SEL_THREADS) void ivf_select_list_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
+                                                                      const int* __restrict__ cnt, const uint64_t* __restrict__ list,
+                                                                      int nprobe, int k, int kp, int64_t id_base,
+                                                                      const float* __restrict__ master, const float* __restrict__ qn, int K,
+                                                                      float* __restrict__ cos_out, int64_t* __restrict__ id_out, int* __restrict__ fallback) {
+    __shared__ uint64_t keys[IVF_LIST_CAP];
+    __shared__ uint64_t top[MAX_KP];
+    __shared__ int s_total;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    for (int p = tid; p < nprobe; p += SEL_THREADS) {
+        const int64_t L = probes[(size_t)q * nprobe + p];
+        if (L >= 0) atomicAdd(&s_total, (int)(offsets[L + 1] - offsets[L]));
+    }
+    __syncthreads();
+    const int n = cnt[q];
+    if (n > IVF_LIST_CAP || n < min(kp, s_total)) {
+        if (tid == 0) atomicExch(fallback, 1);
+        return;
+    }
+    for (int i = tid; i < n; i += SEL_THREADS) keys[i] = list[(size_t)q * IVF_LIST_CAP + i];
+    __syncthreads();
+    const int m = min(n, kp);
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const uint64_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += keys[j] > ki ? 1 : 0;
+        if (rank < kp) top[rank] = ki;
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const float4* qv = reinterpret_cast<const float4*>(qn + (size_t)q * K);
+        const int nvec = K >> 2;
+        for (int e = wave; e < m; e += SEL_WAVES) {
+            const uint32_t row = key_row(top[e]);
+            const float4* rv = reinterpret_cast<const float4*>(master + (size_t)row * K);
+            float sc = 0.f;
+            for (int v4 = lane; v4 < nvec; v4 += 64) {
+                const float4 a = rv[v4], b = qv[v4];
+                sc = fmaf(a.x, b.x, sc); sc = fmaf(a.y, b.y, sc); sc = fmaf(a.z, b.z, sc); sc = fmaf(a.w, b.w, sc);
+            }
+            sc = wave_sum(sc) + 0.0f;
+            if (lane == 0) keys[e] = make_key(sc, row);          // (keys[] is free: the estimates have been ranked)
+        }
+    }
+    __syncthreads();
+    const int mk = min(m, k);
+    for (int i = tid; i < m; i += SEL_THREADS) {
+        const uint64_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += keys[j] > ki ? 1 : 0;
+        if (rank < k) {
+            cos_out[(size_t)q * k + rank] = key_score(ki);
+            id_out[(size_t)q * k + rank] = (int64_t)key_row(ki) + id_base;
+        }
+    }
+    for (int i = mk + tid; i < k; i += SEL_THREADS) {
+        cos_out[(size_t)q * k + i] = -INFINITY;
+        id_out[(size_t)q * k + i] = -1;
+    }
+}
+
 uint64_t splitmix(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1050,8 +1278,11 @@ struct IvfState {
     int64_t i8_cap = 0, i8_done = 0, total_tiles = 0;    // i8_cap: tiles allocated
     int64_t i8_tile_stride = 0;
     bool use_i8 = true;              // knobs build: SQE_IVF_I8=0 keeps the bf16 list scan (A/B)
-    Buf units4, units1;              // work units of the streaming list scan: (list, first tile in the list, tiles, 0), <= 4 tiles / 1 tile each
+    Buf units4, units1;              // work units of the streaming list scan: (list, first tile in the list, tiles, 0), <= ST_UNIT_TILES tiles / 1 tile each
     int n_units4 = 0, n_units1 = 0;
+    Buf unitsS, unitsR;              // collect mode: the first tile of every list (the sample) / the other tiles in runs of <= 4
+    int n_unitsS = 0, n_unitsR = 0;
+    Buf cthr, ccnt, clist, cflag;    // collect mode, per search: thresholds [B], list lengths [B], lists [B, IVF_LIST_CAP], fallback flag
     Buf qn, qb, qd, cent_bf16, cscores, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
 };
@@ -1202,17 +1433,35 @@ static int ivf_build_lists(sqe_index* base, IvfState* st, hipStream_t s) {
     {
         // work units of the streaming list scan (ivf_list_stream_i8_kernel): runs of <= ST_UNIT_TILES tiles of one list, and single tiles
         // (the grid of a search with a handful of queries, where few lists are probed and every CU should get some of them)
-        std::vector<int4> u4, u1;
+        std::vector<int4> u4, u1, uS, uR;
         for (int i = 0; i < nlist; ++i) {
             const int nt = (h_counts[i] + 255) / 256;
-            for (int t0 = 0; t0 < nt; t0 += ST_UNIT_TILES) u4.push_back(make_int4(i, t0, std::min(ST_UNIT_TILES, nt - t0), 0));
+            // (tiles [lo, nt) of a list in nearly equal runs of <= ST_UNIT_TILES: a unit pays its query load and the fill and drain of
+            // its register ring once, so 9 tiles are 5 + 4, not 4 + 4 + 1)
+            auto split = [&](std::vector<int4>& out, int lo) {
+                const int rem = nt - lo;
+                if (rem <= 0) return;
+                const int nu = (rem + ST_UNIT_TILES - 1) / ST_UNIT_TILES;
+                for (int u = 0, t0 = lo; u < nu; ++u) {
+                    const int len = rem / nu + (u < rem % nu ? 1 : 0);
+                    out.push_back(make_int4(i, t0, len, 0));
+                    t0 += len;
+                }
+            };
+            split(u4, 0);
             for (int t0 = 0; t0 < nt; ++t0) u1.push_back(make_int4(i, t0, 1, 0));
+            if (nt > 0) uS.push_back(make_int4(i, 0, 1, 0));
+            split(uR, 1);
         }
-        st->n_units4 = (int)u4.size(); st->n_units1 = (int)u1.size();
+        st->n_units4 = (int)u4.size(); st->n_units1 = (int)u1.size(); st->n_unitsS = (int)uS.size(); st->n_unitsR = (int)uR.size();
         SQE_TRY(st->units4.ensure(std::max<size_t>(1, u4.size()) * sizeof(int4)));
         SQE_TRY(st->units1.ensure(std::max<size_t>(1, u1.size()) * sizeof(int4)));
+        SQE_TRY(st->unitsS.ensure(std::max<size_t>(1, uS.size()) * sizeof(int4)));
+        SQE_TRY(st->unitsR.ensure(std::max<size_t>(1, uR.size()) * sizeof(int4)));
         if (!u4.empty()) SQE_HIP(hipMemcpyAsync(st->units4.p, u4.data(), u4.size() * sizeof(int4), hipMemcpyHostToDevice, s));
         if (!u1.empty()) SQE_HIP(hipMemcpyAsync(st->units1.p, u1.data(), u1.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        if (!uS.empty()) SQE_HIP(hipMemcpyAsync(st->unitsS.p, uS.data(), uS.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        if (!uR.empty()) SQE_HIP(hipMemcpyAsync(st->unitsR.p, uR.data(), uR.size() * sizeof(int4), hipMemcpyHostToDevice, s));
         SQE_HIP(hipStreamSynchronize(s));                 // (host vectors)
     }
     SQE_HIP(hipStreamSynchronize(s));
@@ -1345,11 +1594,46 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         if (!staged && dim % (64 * ST_SL) == 0 && st_lds <= 80 * 1024 && st->n_units4 > 0) {      // (two workgroups per CU)
             // streaming form: one workgroup per unit of <= 4 tiles (single tiles when only a handful of lists are probed)
             const bool few = B * nprobe <= 512;
-            SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_stream_i8_kernel), (int)st_lds));
-            hipLaunchKernelGGL(ivf_list_stream_i8_kernel, dim3(few ? st->n_units1 : st->n_units4), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(),
-                               tile_stride, st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit,
-                               (few ? st->units1 : st->units4).as<int4>(), st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(),
-                               st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len, st->pair_scores.as<float>());
+            static const bool strips_only = [] { const char* e = knob_env("SQE_IVF_STRIPS"); return e && e[0] == '1'; }();   // knobs build: r04a's form, for A/B
+            auto strips = ivf_list_stream_i8_kernel<false>;
+            auto collect = ivf_list_stream_i8_kernel<true>;
+            SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(strips), (int)st_lds));
+            SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(collect), (int)st_lds));
+            auto launch_strips = [&](const Buf& units, int n_units, const int* gate) {
+                hipLaunchKernelGGL(strips, dim3(n_units), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride, st->i8sxi.as<uint32_t>(),
+                                   st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, units.as<int4>(), st->tile_off.as<int64_t>(),
+                                   st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                                   st->pair_scores.as<float>(), StCollect{}, gate);
+            };
+            if (!few && !strips_only && nprobe <= 32 && st->n_unitsR > 0) {
+                // ---- collect mode (r04b): sample pass over the first tile of every list -> per-query thresholds -> the other tiles keep only
+                // the keys at or above them -> the lists are ranked.  Any query whose list cannot answer sets the flag, and the two gated
+                // launches at the end redo the batch through the strips (they return at once otherwise).
+                SQE_TRY(st->cthr.ensure((size_t)B * 4));
+                SQE_TRY(st->ccnt.ensure((size_t)B * 4));
+                SQE_TRY(st->clist.ensure((size_t)B * IVF_LIST_CAP * 8));
+                SQE_TRY(st->cflag.ensure(16));
+                SQE_HIP(hipMemsetAsync(st->cflag.p, 0, 16, s));
+                launch_strips(st->unitsS, st->n_unitsS, nullptr);
+                hipLaunchKernelGGL(ivf_threshold_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
+                                   st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, kp, st->cthr.as<float>(), st->ccnt.as<int>(),
+                                   st->clist.as<uint64_t>());
+                StCollect col{st->cthr.as<float>(), st->ccnt.as<int>(), st->clist.as<uint64_t>(), IVF_LIST_CAP, st->order.as<int>()};
+                hipLaunchKernelGGL(collect, dim3(st->n_unitsR), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride, st->i8sxi.as<uint32_t>(),
+                                   st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->unitsR.as<int4>(), st->tile_off.as<int64_t>(),
+                                   st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                                   st->pair_scores.as<float>(), col, (const int*)nullptr);
+                hipLaunchKernelGGL(ivf_select_list_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
+                                   st->ccnt.as<int>(), st->clist.as<uint64_t>(), nprobe, k, kp, base->id_base, base->master, st->qn.as<float>(), dim,
+                                   cos_out, id_out, st->cflag.as<int>());
+                launch_strips(st->units4, st->n_units4, st->cflag.as<int>());
+                hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
+                                   st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, base->id_base,
+                                   base->master, st->qn.as<float>(), dim, cos_out, id_out, st->cflag.as<int>());
+                SQE_HIP(hipGetLastError());
+                return SQE_OK;
+            }
+            launch_strips(few ? st->units1 : st->units4, few ? st->n_units1 : st->n_units4, nullptr);
         } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
         // a handful of queries: pair mode (the kernel's comment), up to 16 workgroups per probed list
@@ -1368,7 +1652,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     }
     hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                        st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, base->id_base,
-                       base->master, st->qn.as<float>(), dim, cos_out, id_out);
+                       base->master, st->qn.as<float>(), dim, cos_out, id_out, (const int*)nullptr);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }

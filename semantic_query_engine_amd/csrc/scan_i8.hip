@@ -26,6 +26,8 @@
 //   * the 256 row scales of a tile (1 KiB) arrive through one extra LDS-DMA piece per tile.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "scan_common.h"
 
 namespace sqe {
@@ -995,6 +997,177 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_i8_small_kernel(I8KernelArg
     for (int i = tid; i < BN; i += SCAN_THREADS) p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (<= 128 queries), r04: the STREAMING form.  The staged kernel above is HBM-bound at 0.73-0.77 of the peak: every K step
+// of a tile passes through a three-stage LDS ring behind one workgroup barrier, two stages (64 KiB) in flight per CU.  But the tiled
+// copy holds the A operand of v_mfma_i32_16x16x64_i8 for 16 consecutive rows and one 64-byte K slice as ONE contiguous KiB (row r of
+// slice h at h x 16 KiB + r x 64; lane l wants row l & 15, bytes (l >> 4) * 16), so a wave loads a fragment with a single
+// global_load_dwordx4 ... nt straight into the operand registers (ivf.hip has the same stream over the list-ordered copy).  Here:
+//   * the workgroup's BN queries sit in LDS for the whole chunk (BN x (K + 128) bytes, swizzled as the staged images are);
+//   * wave w streams rows 32 w .. 32 w + 31 of every tile through a register ring of RING fragments (RING KiB in flight per wave:
+//     128-256 KiB per CU) -- plain loads, hipcc counts the vmcnt waits; the refill is unconditional inside the steady loop and the
+//     chunk's last group of slices is code of its own (a branch around the loads would make the compiler drain the ring at every join);
+//   * no barrier in the loop: the waves of a workgroup drift apart as the memory system lets them;
+//   * survivors of a finished tile go to a wave-private LDS buffer (ballot + prefix: no atomics) and are appended to the (chunk, query)
+//     lists only when it fills up and at the end of the chunk: vector-memory operations retire in issue order, so a row fragment loaded
+//     behind a key store could not be consumed before that store was acknowledged (ivf.hip measured that stall: 20 % of its kernel).
+// Same collect semantics and the same lists as every other kernel of this file (tests/test_i8_exact_gpu.py compares the key sets).
+template <int BN, int RING>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_i8_stream_kernel(I8KernelArgs p) {
+    constexpr int FN = BN / 16;                       // query fragments: every wave scores all BN queries against its 32 rows
+    constexpr int SL = RING / 2;                      // K slices the ring holds (two 16-row fragments per slice)
+    constexpr int WB = 192;                           // keys of a wave's buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int qrow = p.K + 128;                       // LDS pitch of a query row: rows r and r + 1 start 32 banks apart
+    int* cnt = reinterpret_cast<int*>(smem + BN * qrow);                                  // [BN] list lengths
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t* wkey = reinterpret_cast<uint64_t*>(cnt + BN) + wave * WB;                   // [8][WB] keys waiting for their stores
+    unsigned char* wcol = reinterpret_cast<unsigned char*>(reinterpret_cast<uint64_t*>(cnt + BN) + SCAN_NWAVES * WB) + wave * WB;
+    int logical = blockIdx.x;
+    const int G = gridDim.x;
+    if ((G & 7) == 0) logical = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = __builtin_amdgcn_readfirstlane(logical / p.qblocks);
+    const int qb = __builtin_amdgcn_readfirstlane(logical % p.qblocks);
+    const int q0 = qb * BN;
+    int tile_begin, tile_end;
+    chunk_tile_range(p.n_tiles, p.n_chunks, chunk, tile_begin, tile_end);
+    const int nt = tile_end - tile_begin;
+    const int HS = p.K >> 6;                          // (a multiple of SL: the launcher checks)
+    const int GPT = HS / SL;                          // groups of slices per tile
+    uint64_t* cand_base = p.cand + ((size_t)chunk * p.b_pad + q0) * CAND_CAP;
+    const int q_live = min(BN, p.B - q0);
+
+    // ---- the queries into LDS: chunk cc of row r at r * qrow + ((cc ^ ((r >> 1) & 7)) << 4)
+    {
+        const int cpr = p.K >> 4;
+        const char* qsrc = reinterpret_cast<const char*>(p.q8) + (size_t)q0 * p.q_pitch;
+        for (int c = tid; c < BN * cpr; c += SCAN_THREADS) {
+            const int r = c / cpr, cc = c - r * cpr;
+            const i32x4 v = *reinterpret_cast<const i32x4*>(qsrc + (size_t)r * p.q_pitch + cc * 16);
+            *reinterpret_cast<i32x4*>(smem + r * qrow + ((cc ^ ((r >> 1) & 7)) << 4)) = v;
+        }
+        for (int i = tid; i < BN; i += SCAN_THREADS) cnt[i] = 0;
+    }
+    int thr[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) thr[j] = p.thr_int[q0 + j * 16 + (lane & 15)];
+    __syncthreads();
+    if (nt > 0) {
+        const char* abase = reinterpret_cast<const char*>(p.db8) + (long long)tile_begin * p.tile_stride + wave * 2048;
+        const unsigned aoff = (unsigned)((lane & 15) * 64 + (lane >> 4) * 16);
+        const int br = lane & 15, bsw = (br >> 1) & 7, bcq = lane >> 4;
+        const char* bbase = smem + br * qrow;
+        // issue cursor: the next K slice (both 16-row halves of the wave's rows)
+        const char* ctile = abase;
+        int ch = 0;
+        auto issue_slice = [&](i32x4* r) {
+            const char* ptr = ctile + (size_t)ch * 16384 + aoff;
+            r[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(ptr));
+            r[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(ptr + 1024));
+            if (++ch == HS) { ch = 0; ctile += p.tile_stride; }
+        };
+        i32x4 ring[RING];
+#pragma unroll
+        for (int e = 0; e < SL; ++e) issue_slice(&ring[2 * e]);
+        i32x4 acc[2][FN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+        // SL slices against the resident queries; ISSUE: a slice's registers are refilled as soon as they have been read
+        auto group = [&](int hb, auto issue_tag) {
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            const char* bq = bbase + hb * 64;
+#pragma unroll
+            for (int e = 0; e < SL; ++e) {
+                const int boff = ((e * 4 + bcq) ^ bsw) << 4;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const i32x4 b = *reinterpret_cast<const i32x4*>(bq + j * 16 * qrow + boff);
+                    acc[0][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[2 * e], b, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[2 * e + 1], b, acc[1][j], 0, 0, 0);
+                }
+                if (ISSUE) issue_slice(&ring[2 * e]);
+            }
+        };
+        int wn = 0;                                   // keys in this wave's buffer (wave-uniform)
+        auto flush = [&]() {
+            for (int i = lane; i < wn; i += 64) {
+                const uint64_t key = wkey[i];
+                const int qcol = wcol[i];
+                const int slot = atomicAdd(&cnt[qcol], 1);
+                if (slot < CAND_CAP) cand_base[(size_t)qcol * CAND_CAP + slot] = key;
+                else {                                // the list is full: the query's pool (kernels.h: I8_OVF_CAP)
+                    const int o = atomicAdd(&p.ovf_cnt[q0 + qcol], 1);
+                    if (o < I8_OVF_CAP) p.ovf[(size_t)(q0 + qcol) * I8_OVF_CAP + o] = key;
+                }
+            }
+            wn = 0;
+        };
+        // survivors of a finished tile -> the wave's buffer; the exact predicate acc * s >= thr, fragment by fragment (collect_group)
+        auto tile_done = [&](int t) {
+            const int scale = (int)p.sxi[(size_t)(tile_begin + t) * SCAN_BM];          // one scale per tile (quant.hip); a scalar load
+            const int64_t row0 = (int64_t)(tile_begin + t) * SCAN_BM + wave * 32 + (lane >> 4) * 4;
+            const bool partial = (int64_t)(tile_begin + t + 1) * SCAN_BM > p.n_rows;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int qcol = j * 16 + (lane & 15);
+                const bool live = qcol < q_live;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const i32x4 v = acc[i][j];
+                    const int m4 = max(max(max(v[0], v[1]), v[2]), v[3]);
+                    const bool hit = live && __mul24(m4, scale) >= thr[j];
+                    if (__any(hit)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int sc = __mul24(v[e], scale);
+                            const int64_t row = row0 + i * 16 + e;
+                            const bool ok = hit && sc >= thr[j] && (!partial || row < p.n_rows);
+                            const unsigned long long mask = __ballot(ok);
+                            if (mask == 0ull) continue;
+                            if (wn + 64 > WB) flush();                              // (wave-uniform)
+                            if (ok) {
+                                const int at = wn + __popcll(mask & ((1ull << lane) - 1ull));
+                                wkey[at] = make_key_i32(sc, (uint32_t)row);
+                                wcol[at] = (unsigned char)qcol;
+                            }
+                            wn += __popcll(mask);
+                        }
+                    }
+                    acc[i][j] = i32x4{0, 0, 0, 0};
+                }
+            }
+        };
+        const int n_grp = nt * GPT;
+        int gt = 0, t = 0;
+        for (int g = 0; g + 1 < n_grp; ++g) {
+            group(gt * SL, std::true_type{});
+            if (++gt == GPT) {
+                tile_done(t);
+                gt = 0;
+                ++t;
+            }
+        }
+        group(gt * SL, std::false_type{});
+        tile_done(t);
+        flush();
+    }
+    __syncthreads();
+    for (int i = tid; i < BN; i += SCAN_THREADS) p.cand_cnt[(size_t)chunk * p.b_pad + q0 + i] = cnt[i];
+}
+
+template <int BN, int RING>
+int launch_stream(const I8KernelArgs& k, hipStream_t stream) {
+    const int lds = BN * (k.K + 128) + BN * 4 + SCAN_NWAVES * 192 * 9;
+    auto kern = scan_i8_stream_kernel<BN, RING>;
+    SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(k.n_chunks * k.qblocks), dim3(SCAN_THREADS), lds, stream, k);
+    SQE_HIP(hipGetLastError());
+    return SQE_OK;
+}
+
 template <int WM, int WN, int FM, int FN, int NST, int NSTB>
 int launch_small(const I8KernelArgs& k, hipStream_t stream) {
     constexpr int BN = WN * FN * 16;
@@ -1022,6 +1195,17 @@ int launch_scan_i8(const I8ScanArgs& a, hipStream_t stream) {
         static const int force = [] { const char* e = knob_env("SQE_I8_SYNC"); return e ? (e[0] == '0' ? 1 : 2) : 0; }();   // knobs build only
         static const int xdbg = [] { const char* e = knob_env("SQE_I8_DBG"); return e ? atoi(e) : 0; }();
         k.dbg = force | (xdbg << 3);
+    }
+    {
+        // the streaming kernels wherever the queries fit in LDS beside the buffers (dim 1024: both; up to 2,048 for 64 queries) and the
+        // slices of a row divide into ring groups; the staged kernels otherwise (knobs build, SQE_I8_STAGED=1: always, for A/B)
+        static const bool staged = [] { const char* e = knob_env("SQE_I8_STAGED"); return e && e[0] == '1'; }();
+        const int lds = a.bn * (a.K + 128) + a.bn * 4 + SCAN_NWAVES * 192 * 9;
+        if (!staged && a.bn <= 128 && lds <= 160 * 1024) {
+            if (a.bn == 64 && a.K % 1024 == 0) return launch_stream<64, 32>(k, stream);
+            if (a.bn == 64 && a.K % 512 == 0) return launch_stream<64, 16>(k, stream);
+            if (a.bn == 128 && a.K % 512 == 0) return launch_stream<128, 16>(k, stream);     // (a 32-fragment ring spills here: 256 VGPRs)
+        }
     }
     if (a.bn == 64) return launch_small<8, 1, 2, 4, 3, 3>(k, stream);          // the tilings of scan.hip's 64- / 128-query kernels
     if (a.bn == 128) return launch_small<4, 2, 4, 4, 3, 2>(k, stream);

@@ -115,3 +115,41 @@ def test_ivf_int8_list_scan_pair_and_list_modes(ctx):
             cos, ids = idx.search(q[:b], k, nprobe=nprobe)
             ref_cos, ref_ids = R.ivf_search(xn, qn[:b], centroids, assign, k, nprobe)
             assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn[:b])
+
+
+def test_ivf_collect_mode_and_its_fallback(ctx):
+    """Batches of more than 512 (query, probe) pairs run the int8 list scan in COLLECT mode (ivf.hip, r04b): a sample pass over the first
+    tile of every list gives each query a threshold, the pass over the other tiles keeps only the keys at or above it, and
+    ivf_select_list_kernel ranks a few hundred keys instead of ~nprobe x list-length scores.  The kept set contains the kp best
+    estimates, so the answer is the strip path's: compared with oracle.ivf_search on the exported structure.  Then 10,000 copies of one
+    vector go into one list: the queries aimed at it find more keys at their threshold than a list holds (8,192), raise the fallback
+    flag, and the gated strip-mode launches answer the batch -- still the oracle's result (copies have identical cosines: any is right)."""
+    from semantic_query_engine_amd import INDEX_IVF_FLAT, VectorIndex
+    n, d, k, nlist, nprobe, b = 120_000, 256, 10, 32, 8, 200
+    x, cen = _clustered(n, d, 100, seed=11)
+    rng = np.random.default_rng(12)
+    q = (x[rng.integers(0, n, b)] + 0.2 * rng.standard_normal((b, d))).astype(np.float32)
+    idx = VectorIndex(ctx, d, INDEX_IVF_FLAT, nlist)
+    idx.train(x[:40000], iters=6, seed=13)
+    idx.add(x)
+    centroids, assign = idx.ivf_export(nlist)
+    assert np.bincount(assign, minlength=nlist).min() > 512            # every list has tiles beyond the sample tile
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    cos, ids = idx.search(q, k, nprobe=nprobe)
+    ref_cos, ref_ids = R.ivf_search(xn, qn, centroids, assign, k, nprobe)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
+    c1, i1 = idx.search(q[:3], k, nprobe=nprobe)                        # 24 pairs: the strip path (single tiles) -- same answers
+    assert np.array_equal(i1, ids[:3]) and np.allclose(c1, cos[:3], atol=2e-6)
+    # ---- a crowd of copies: the list overflows for the queries aimed at it
+    v = rng.standard_normal(d).astype(np.float32)                       # (far from every cluster: only the queries aimed at it see the copies --
+    rows = rng.permutation(n)[:10000]                                   #  thousands of ties inside a cluster would crowd its members' kp = 40 estimates)
+    x[rows] = v
+    idx.update(rows, x[rows])
+    q[:10] = v + 0.01 * rng.standard_normal((10, d)).astype(np.float32)
+    centroids, assign = idx.ivf_export(nlist)
+    xn, qn = R.normalize_rows(x), R.normalize_rows(q)
+    cos, ids = idx.search(q, k, nprobe=nprobe)
+    ref_cos, ref_ids = R.ivf_search(xn, qn, centroids, assign, k, nprobe)
+    assert_topk_matches(cos, ids, ref_cos, ref_ids, xn, qn)
+    assert np.all(np.isin(ids[:10], rows))
+    idx.close()
