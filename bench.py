@@ -444,7 +444,8 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None}
-        kernel = ("scan_i8_pp_kernel" if b > 128 else "scan_i8_small_kernel") if used_i8 else \
+        # (dim 1024: batches <= 128 run the streaming kernel, one 256-query block the five-stage build of the ping-pong kernel)
+        kernel = ("scan_i8_pp_kernel" if b > 256 else "scan_i8_pp_deep_kernel" if b > 128 else "scan_i8_stream_kernel") if used_i8 else \
                  ("scan_bf16_pp_kernel" if b > 128 else "scan_bf16_kernel")
         roof.update({"kernel": kernel, "kernel_ms": round(scan_ms, 4), "launches": int(st["scan_calls"]),
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,

@@ -710,9 +710,21 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
                                                                         const int4* __restrict__ units, const int64_t* __restrict__ tile_off,
                                                                         const int64_t* __restrict__ offsets, const int* __restrict__ lcount,
                                                                         const int* __restrict__ lq, int cap, int nprobe, int K, int max_len,
-                                                                        float* __restrict__ pair_scores, StCollect col, const int* __restrict__ gate) {
+                                                                        float* __restrict__ pair_scores, StCollect col, const int* __restrict__ gate,
+                                                                        int* __restrict__ queue, int n_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_next;
     if (gate && *gate == 0) return;                            // (the strip-mode fallback of a collect search: only if some query asked for it)
+    // queue != null: PERSISTENT workgroups (two per CU) take units from a counter -- ~12 k workgroups of ~100 us each otherwise, and the
+    // stream read at 5.5 TB/s where the flat small-batch kernel, persistent, reads at 6.5
+    for (int unit = blockIdx.x;;) {
+    if (queue) {
+        __syncthreads();                                       // (the previous unit is done with LDS)
+        if (threadIdx.x == 0) s_next = atomicAdd(queue, 1);
+        __syncthreads();
+        unit = s_next;
+    }
+    if (unit >= n_units) return;
     const int qrow = K + 128;                                  // LDS pitch of a query row: rows r and r + 1 start 32 banks apart
     float* sscale = reinterpret_cast<float*>(smem + ST_Q * qrow);          // [ST_UNIT_TILES * 256] row scales of the unit
     int* spair = reinterpret_cast<int*>(sscale + ST_UNIT_TILES * LS_ROWS);
@@ -724,10 +736,13 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
     unsigned char* cbuf_col = reinterpret_cast<unsigned char*>(cbuf_key + ST_CBUF);
     int* cbuf_n = reinterpret_cast<int*>(cbuf_col + ST_CBUF);
     float* sthr = reinterpret_cast<float*>(cbuf_n + 4);        // [ST_Q]
-    const int4 u = units[blockIdx.x];
+    const int4 u = units[unit];
     const int L = u.x, ntiles = u.z;
     const int m = min(lcount[L], cap);
-    if (m == 0) return;                                        // nobody probes this list
+    if (m == 0) {                                              // nobody probes this list
+        if (!queue) return;
+        continue;
+    }
     const int len_all = (int)(offsets[L + 1] - offsets[L]);
     const int row0 = u.y * LS_ROWS;                            // first row of the unit inside its list
     const int64_t gt0 = tile_off[L] + u.y;                     // ... and its first tile in the copy
@@ -897,6 +912,8 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
                 if (slot < col.list_cap) col.list[(size_t)q * col.list_cap + slot] = make_key(key_score(key), (uint32_t)col.order[off + key_row(key)]);
             }
         }
+    }
+    if (!queue) return;
     }
 }
 
@@ -1599,11 +1616,14 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
             auto collect = ivf_list_stream_i8_kernel<true>;
             SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(strips), (int)st_lds));
             SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(collect), (int)st_lds));
-            auto launch_strips = [&](const Buf& units, int n_units, const int* gate) {
-                hipLaunchKernelGGL(strips, dim3(n_units), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride, st->i8sxi.as<uint32_t>(),
-                                   st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, units.as<int4>(), st->tile_off.as<int64_t>(),
-                                   st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
-                                   st->pair_scores.as<float>(), StCollect{}, gate);
+            static const bool no_queue = [] { const char* e = knob_env("SQE_IVF_QUEUE"); return e && e[0] == '0'; }();   // knobs build: one workgroup per unit, for A/B
+            const int persistent = 2 * base->ctx->cu_count;                  // two workgroups per CU
+            auto launch_strips = [&](const Buf& units, int n_units, const int* gate, int* queue) {
+                if (no_queue || n_units <= persistent) queue = nullptr;
+                hipLaunchKernelGGL(strips, dim3(queue ? persistent : n_units), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride,
+                                   st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, units.as<int4>(),
+                                   st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                                   st->pair_scores.as<float>(), StCollect{}, gate, queue, n_units);
             };
             if (!few && !strips_only && nprobe <= 32 && st->n_unitsR > 0) {
                 // ---- collect mode (r04b): sample pass over the first tile of every list -> per-query thresholds -> the other tiles keep only
@@ -1614,26 +1634,27 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                 SQE_TRY(st->clist.ensure((size_t)B * IVF_LIST_CAP * 8));
                 SQE_TRY(st->cflag.ensure(16));
                 SQE_HIP(hipMemsetAsync(st->cflag.p, 0, 16, s));
-                launch_strips(st->unitsS, st->n_unitsS, nullptr);
+                launch_strips(st->unitsS, st->n_unitsS, nullptr, st->cflag.as<int>() + 1);      // (cflag: [0] fallback flag, [1..3] unit counters)
                 hipLaunchKernelGGL(ivf_threshold_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                                    st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, kp, st->cthr.as<float>(), st->ccnt.as<int>(),
                                    st->clist.as<uint64_t>());
                 StCollect col{st->cthr.as<float>(), st->ccnt.as<int>(), st->clist.as<uint64_t>(), IVF_LIST_CAP, st->order.as<int>()};
-                hipLaunchKernelGGL(collect, dim3(st->n_unitsR), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride, st->i8sxi.as<uint32_t>(),
-                                   st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->unitsR.as<int4>(), st->tile_off.as<int64_t>(),
-                                   st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
-                                   st->pair_scores.as<float>(), col, (const int*)nullptr);
+                int* cqueue = (no_queue || st->n_unitsR <= persistent) ? nullptr : st->cflag.as<int>() + 2;
+                hipLaunchKernelGGL(collect, dim3(cqueue ? persistent : st->n_unitsR), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride,
+                                   st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->unitsR.as<int4>(),
+                                   st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
+                                   st->pair_scores.as<float>(), col, (const int*)nullptr, cqueue, st->n_unitsR);
                 hipLaunchKernelGGL(ivf_select_list_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                                    st->ccnt.as<int>(), st->clist.as<uint64_t>(), nprobe, k, kp, base->id_base, base->master, st->qn.as<float>(), dim,
                                    cos_out, id_out, st->cflag.as<int>());
-                launch_strips(st->units4, st->n_units4, st->cflag.as<int>());
+                launch_strips(st->units4, st->n_units4, st->cflag.as<int>(), st->cflag.as<int>() + 3);
                 hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                                    st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, base->id_base,
                                    base->master, st->qn.as<float>(), dim, cos_out, id_out, st->cflag.as<int>());
                 SQE_HIP(hipGetLastError());
                 return SQE_OK;
             }
-            launch_strips(few ? st->units1 : st->units4, few ? st->n_units1 : st->n_units4, nullptr);
+            launch_strips(few ? st->units1 : st->units4, few ? st->n_units1 : st->n_units4, nullptr, nullptr);
         } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
         // a handful of queries: pair mode (the kernel's comment), up to 16 workgroups per probed list

@@ -29,6 +29,9 @@ elif [ "$part" = "3" ]; then
   find $out/enc_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/enc_64x512_kernel_stats.csv; rm -rf $out/enc_prof
   python tools/enc_small.py > $out/enc_small.jsonl 2> $out/enc_small.err; cat $out/enc_small.jsonl | cut -c1-160
   python tools/latency_b1.py > $out/latency_b1.json 2> $out/latency_b1.err; cat $out/latency_b1.json
+  # one 1 x 16-token forward, kernel by kernel (execution time against launch gaps)
+  rocprofv3 --kernel-trace --output-format csv -d $out/b1_prof -- python3 tools/latency_b1.py > /dev/null 2> $out/b1_prof.err
+  python3 tools/trace_forward.py $out/b1_prof 10 | tee $out/enc_1x16_forward_trace.txt; rm -rf $out/b1_prof
   # IVF: the sweep, then its kernel trace (longest dispatch of a kernel = the batch-1024 search, shortest list scan = batch 1) and HBM traffic
   tools/r04_ivf_ab.sh $out ""
   for pass in FETCH_SIZE WRITE_SIZE; do

@@ -27,7 +27,8 @@ for n, v in sorted(dur.items(), key=lambda kv: -max(kv[1])):
     if n.startswith('ivf_') or 'gemm_ring' in n or 'normalize' in n or 'quantize_rows' in n:
         print(f"   {n:46s} dispatches {len(v):5d}   longest {max(v):9.1f} us (batch 1024)   shortest {min(v):7.1f} us (batch 1)")
 # the kernels of the LAST batch-1 search of the run (the sweep ends with the flat index: take the last ivf_select whose strip pass was short)
-sel = [i for i, r in enumerate(rows) if 'ivf_select_kernel' in r['Kernel_Name']]
+# (a gated strip select of the collect mode is a ~4 us no-op: only dispatches that did work count)
+sel = [i for i, r in enumerate(rows) if 'ivf_select_kernel' in r['Kernel_Name'] and int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 10000]
 one = min(sel, key=lambda i: int(rows[i]['End_Timestamp']) - int(rows[i]['Start_Timestamp']))
 j = one
 while j > 0 and 'ivf_select_kernel' not in rows[j - 1]['Kernel_Name'] and one - j < 12: j -= 1
