@@ -149,12 +149,14 @@ __global__ __launch_bounds__(PSEL_THREADS) void ivf_probe_select_kernel(const fl
         {
             int hb, hr;
             hist_locate(hist, remaining, hb, hr);
-            if (tid == 0) { scratch[0] = hb < 0 ? 0 : hb; scratch[1] = hr; }
+            if (tid == 0) { scratch[0] = hb < 0 ? 0 : hb; scratch[1] = hr; scratch[3] = hb < 0 ? 0 : hist[hb]; }
         }
         __syncthreads();
         prefix |= ((uint64_t)scratch[0] << shift);
         remaining = scratch[1];
+        const bool whole_bin = scratch[3] == remaining;       // keys are unique: every key of the located bin is wanted -> keys >= prefix are the nsel best
         __syncthreads();
+        if (whole_bin) break;                                  // (r04c: three or four passes of the eight on scores that differ)
     }
     const uint64_t T = all ? 0ull : prefix;
     if (tid == 0) scratch[2] = 0;
@@ -656,15 +658,23 @@ constexpr int ST_PATCH_ROWS = 36;         // query rows of patch per wave: four 
 struct StCursor {
     const char* tile;                     // base of the cursor's tile (+ the wave's rows)
     int h;                                // its K slice
+    // r04c: a list ends inside its last tile (2,441 rows on average = 9.5 tiles: 5 % of the copy is padding).  The wave's fragments of
+    // that tile that lie wholly behind the list's end are read from `dummy` -- a KiB every unit keeps hot in L2 (the head of the query
+    // block) -- instead of from HBM: their scores are dropped by the row < len tests anyway.  A select on the address, no branch.
+    const char* last;                     // the list's last tile if it is partial and belongs to this unit (else null)
+    int nvalid;                           // fragments of this wave in it that hold rows of the list
+    const char* dummy;
 };
 __device__ __forceinline__ void st_issue_slice(StCursor& c, int HS, int64_t tile_stride, unsigned aoff, i32x4_t* r) {
     const char* p = c.tile + (size_t)c.h * 16384 + aoff;
+    const bool pad = c.tile == c.last;
 #pragma unroll
     for (int f = 0; f < ST_FR; ++f) {
+        const char* pf = (pad && f >= c.nvalid) ? c.dummy + aoff : p + f * 1024;
 #ifdef SQE_ST_NO_NT              // (timing build: default cache policy)
-        r[f] = *reinterpret_cast<const i32x4_t*>(p + f * 1024);
+        r[f] = *reinterpret_cast<const i32x4_t*>(pf);
 #else
-        r[f] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(p + f * 1024));
+        r[f] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(pf));
 #endif
     }
     if (++c.h == HS) { c.h = 0; c.tile += tile_stride; }
@@ -743,7 +753,8 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
         if (!queue) return;
         continue;
     }
-    const int len_all = (int)(offsets[L + 1] - offsets[L]);
+    const int64_t loff = offsets[L];
+    const int len_all = (int)(offsets[L + 1] - loff);
     const int row0 = u.y * LS_ROWS;                            // first row of the unit inside its list
     const int64_t gt0 = tile_off[L] + u.y;                     // ... and its first tile in the copy
     const int tid = threadIdx.x, lane = tid & 63;
@@ -752,6 +763,10 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
     const int GPT = HS / ST_SL;                                // groups per tile
     // this lane's 16 bytes of a fragment: row (lane & 15) of a 16-row block, bytes (lane >> 4) * 16 of its slice
     const char* abase = reinterpret_cast<const char*>(scan) + gt0 * tile_stride + wave * (ST_FR * 1024);
+    // (StCursor: the wave's fragments behind the end of the list, when the list's partial last tile is this unit's last)
+    const int list_tiles = (len_all + LS_ROWS - 1) / LS_ROWS;
+    const int pad_nvalid = min(ST_FR, max(0, (len_all - (list_tiles - 1) * LS_ROWS - wave * (ST_FR * 16) + 15) >> 4));
+    const char* pad_tile = (u.y + ntiles == list_tiles && pad_nvalid < ST_FR) ? abase + (int64_t)(ntiles - 1) * tile_stride : nullptr;
 #ifdef SQE_ST_NATURAL            // (timing build, results wrong: lane-contiguous addresses -- what a fragment-major copy would read)
     const unsigned aoff = (unsigned)(lane * 16);
 #else
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
 
         // ---- the stream: group g = slices (g % GPT) * ST_SL .. of tile g / GPT; the ring holds group g while group g + 1 is on its way
         i32x4_t ring[ST_RING];
-        StCursor cur{abase, 0};
+        StCursor cur{abase, 0, pad_tile, pad_nvalid, reinterpret_cast<const char*>(qb)};
 #pragma unroll
         for (int e = 0; e < ST_SL; ++e) st_issue_slice(cur, HS, tile_stride, aoff, &ring[e * ST_FR]);
         i32x4_t acc[ST_FR][2];
@@ -852,7 +867,7 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
                                         const int q = spair[c] / nprobe;
                                         const int slot = atomicAdd(col.cnt + q, 1);
                                         if (slot < col.list_cap)
-                                            col.list[(size_t)q * col.list_cap + slot] = make_key(v[e], (uint32_t)col.order[offsets[L] + trow + r + e]);
+                                            col.list[(size_t)q * col.list_cap + slot] = make_key(v[e], (uint32_t)col.order[loff + trow + r + e]);
                                     }
                                 }
                         }
@@ -904,7 +919,7 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
         if (COLLECT) {
             __syncthreads();                                   // every wave's keys are in the buffer; no load is in flight any more
             const int n = *cbuf_n;
-            const int64_t off = offsets[L];
+            const int64_t off = loff;
             for (int i = tid; i < min(n, ST_CBUF); i += ST_THREADS) {
                 const uint64_t key = cbuf_key[i];
                 const int q = spair[cbuf_col[i]] / nprobe;
@@ -920,9 +935,12 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
 // Threshold of a query for the collect pass, from the sample strips (the first min(256, len) scores of each of its probed lists): the
 // r-th largest sample score, r placed so that ~8 kp rows of the whole probed set are expected at or above it (r = 8 kp x sample
 // fraction, plus three standard deviations of that count and 2), and the sample's own entries at or above it start the query's list.
-// A probed set small enough to fit the list whole gets -inf.  One workgroup of 256 threads per query.
+// A probed set small enough to fit the list whole gets -inf.  One workgroup of 1,024 threads per query (r04c; 256 before: the sample
+// came in as 32 dependent round trips, one strip after the other -- 36 us for a kernel that moves 32 KiB): 32 threads per strip, the
+// eight loads of a thread issued together.
 constexpr int IVF_LIST_CAP = 8192;      // keys of a query's list: a whole cluster of near-ties (2,441 rows in SURVEY 8(d)'s set) must fit
-__global__ __launch_bounds__(256) void ivf_threshold_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
+constexpr int THR_THREADS = 1024;
+__global__ __launch_bounds__(THR_THREADS) void ivf_threshold_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
                                                             const int* __restrict__ order, const float* __restrict__ pair_scores,
                                                             int nprobe, int max_len, int kp, float* __restrict__ thr_out,
                                                             int* __restrict__ cnt, uint64_t* __restrict__ list) {
@@ -948,12 +966,17 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const int64_t* __res
     }
     __syncthreads();
     const int S = s_pos[nprobe], total = scratch[3];
-    for (int p = 0; p < nprobe; ++p) {
-        const int n = s_pos[p + 1] - s_pos[p];
-        const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
-        for (int i = tid; i < n; i += 256) {
-            const float sc = strip[i];
-            samp[s_pos[p] + i] = sc == sc ? f32_orderable(sc + 0.0f) : 0u;      // (NaN rows never rank)
+    {
+        const int p = tid >> 5, sub = tid & 31;                // (nprobe <= 32: the host takes this mode only then)
+        if (p < nprobe) {
+            const int n = s_pos[p + 1] - s_pos[p];
+            const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
+            float v[LS_ROWS / 32];
+#pragma unroll
+            for (int j = 0; j < LS_ROWS / 32; ++j) v[j] = sub + 32 * j < n ? strip[sub + 32 * j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < LS_ROWS / 32; ++j)
+                if (sub + 32 * j < n) samp[s_pos[p] + sub + 32 * j] = v[j] == v[j] ? f32_orderable(v[j] + 0.0f) : 0u;      // (NaN rows never rank)
         }
     }
     __syncthreads();
@@ -964,10 +987,10 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const int64_t* __res
         uint32_t pre = 0;
         int rem = want;
         for (int byte = 3; byte >= 0; --byte) {
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const int shift = byte * 8;
-            for (int i = tid; i < S; i += 256) {
+            for (int i = tid; i < S; i += THR_THREADS) {
                 const uint32_t v32 = samp[i];
                 if (byte == 3 || (v32 >> (shift + 8)) == (pre >> (shift + 8))) atomicAdd(&hist[(v32 >> shift) & 0xff], 1);
             }
@@ -985,19 +1008,23 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const int64_t* __res
         thr = pre;
     }
     // the sample's own entries at or above the threshold open the list
-    for (int p = 0; p < nprobe; ++p) {
-        const int n = s_pos[p + 1] - s_pos[p];
-        for (int i = tid; i < n; i += 256) {
-            const uint32_t v32 = samp[s_pos[p] + i];
-            if (v32 != 0u && v32 >= thr) {
-                const int slot = atomicAdd(&scratch[2], 1);
-                if (slot < IVF_LIST_CAP) list[(size_t)q * IVF_LIST_CAP + slot] = make_key(f32_from_orderable(v32), (uint32_t)order[s_off[p] + i]);
+    {
+        const int p = tid >> 5, sub = tid & 31;
+        if (p < nprobe) {
+            const int n = s_pos[p + 1] - s_pos[p];
+            for (int i = sub; i < n; i += 32) {
+                const uint32_t v32 = samp[s_pos[p] + i];
+                if (v32 != 0u && v32 >= thr) {
+                    const int slot = atomicAdd(&scratch[2], 1);
+                    if (slot < IVF_LIST_CAP) list[(size_t)q * IVF_LIST_CAP + slot] = make_key(f32_from_orderable(v32), (uint32_t)order[s_off[p] + i]);
+                }
             }
         }
     }
     __syncthreads();
     if (tid == 0) {
         cnt[q] = scratch[2];
+        cnt[gridDim.x + q] = total;                            // (ivf_select_list_kernel: a list shorter than min(kp, total) cannot answer)
         thr_out[q] = thr == 0u ? -INFINITY : f32_from_orderable(thr);
     }
 }
@@ -1007,6 +1034,55 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const int64_t* __res
 // 1,024 threads per query (r04; 256 before): the strip passes and the re-score are chains of dependent loads per wave -- one query
 // alone took 83 us here, of a 196 us search (profiles/r04_configs/ivf_stream_ablation.log) -- sixteen waves shorten every chain fourfold.
 constexpr int SEL_THREADS = 1024, SEL_WAVES = SEL_THREADS / 64;
+// fp32 re-score of the kept rows top[0 .. m) against the master: out[e] = (exact cosine, row).  One wave per row; every thread of the
+// block calls (SEL_WAVES waves); out may be top.
+__device__ __forceinline__ void rescore_top(const uint64_t* top, uint64_t* out, int m, const float* __restrict__ master,
+                                            const float* __restrict__ qrow, int K, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const float4* qv = reinterpret_cast<const float4*>(qrow);
+    const int nvec = K >> 2;
+    if (K == 1024 && m <= 3 * SEL_WAVES) {
+        // the usual shape (kp = 40 rows of 4 KiB, sixteen waves): a wave's up to three rows are random rows of the master, each a full
+        // memory round trip (and a TLB miss) -- all their loads are issued before the first sum, one round trip instead of three
+        float4 a[3][4], b[4];
+        uint32_t rows[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = wave + r * SEL_WAVES;
+            rows[r] = e < m ? key_row(top[e]) : 0u;
+            const float4* rv = reinterpret_cast<const float4*>(master + (size_t)rows[r] * K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[r][i] = e < m ? rv[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = qv[lane + 64 * i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = wave + r * SEL_WAVES;
+            float sc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {          // (the order of the general loop below: same bits)
+                sc = fmaf(a[r][i].x, b[i].x, sc); sc = fmaf(a[r][i].y, b[i].y, sc);
+                sc = fmaf(a[r][i].z, b[i].z, sc); sc = fmaf(a[r][i].w, b[i].w, sc);
+            }
+            sc = wave_sum(sc) + 0.0f;
+            if (lane == 0 && e < m) out[e] = make_key(sc, rows[r]);
+        }
+        return;
+    }
+    for (int e = wave; e < m; e += SEL_WAVES) {
+        const uint32_t row = key_row(top[e]);
+        const float4* rv = reinterpret_cast<const float4*>(master + (size_t)row * K);
+        float sc = 0.f;
+        for (int v4 = lane; v4 < nvec; v4 += 64) {
+            const float4 a = rv[v4], b = qv[v4];
+            sc = fmaf(a.x, b.x, sc); sc = fmaf(a.y, b.y, sc); sc = fmaf(a.z, b.z, sc); sc = fmaf(a.w, b.w, sc);
+        }
+        sc = wave_sum(sc) + 0.0f;
+        if (lane == 0) out[e] = make_key(sc, row);
+    }
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
                                                          const int* __restrict__ order, const float* __restrict__ pair_scores,
                                                          int nprobe, int max_len, int k, int kp, int64_t id_base,
@@ -1172,22 +1248,7 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
     __syncthreads();
     const int m = min(scratch[2], kp);
     // fp32 re-score of the kept rows (one wave per row), then rank by the exact cosines
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        const float4* qv = reinterpret_cast<const float4*>(qn + (size_t)q * K);
-        const int nvec = K >> 2;
-        for (int e = wave; e < m; e += SEL_WAVES) {
-            const uint32_t row = key_row(top[e]);
-            const float4* rv = reinterpret_cast<const float4*>(master + (size_t)row * K);
-            float s = 0.f;
-            for (int v4 = lane; v4 < nvec; v4 += 64) {
-                const float4 a = rv[v4], b = qv[v4];
-                s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
-            }
-            s = wave_sum(s) + 0.0f;
-            if (lane == 0) top[e] = make_key(s, row);
-        }
-    }
+    rescore_top(top, top, m, master, qn + (size_t)q * K, K, tid);
     __syncthreads();
     const int mk = min(m, k);
     for (int i = tid; i < m; i += SEL_THREADS) {
@@ -1205,57 +1266,68 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
     }
 }
 
-// Collect mode: the query's list holds every (estimated score, row) at or above its threshold -- a few hundred keys.  The kp best by
-// estimate (rank counting in LDS) are re-scored in fp32 against the master and ranked, as ivf_select_kernel does for the strips.  A
+// Collect mode: the query's list holds every (estimated score, row) at or above its threshold -- a few hundred to a few thousand keys.
+// The kp best by estimate (radix select in LDS) are re-scored in fp32 against the master and ranked, as ivf_select_kernel does for the strips.  A
 // list that overflowed, or holds fewer than kp keys although more rows were probed, cannot answer: the query raises the fallback flag
 // and the strip-mode pass (gated launches behind this kernel) answers the whole batch.
-__global__ __launch_bounds__(SEL_THREADS) void ivf_select_list_kernel(const int64_t* __restrict__ probes, const int64_t* __restrict__ offsets,
-                                                                      const int* __restrict__ cnt, const uint64_t* __restrict__ list,
-                                                                      int nprobe, int k, int kp, int64_t id_base,
+__global__ __launch_bounds__(SEL_THREADS) void ivf_select_list_kernel(const int* __restrict__ cnt, const int* __restrict__ totals,
+                                                                      const uint64_t* __restrict__ list, int k, int kp, int64_t id_base,
                                                                       const float* __restrict__ master, const float* __restrict__ qn, int K,
                                                                       float* __restrict__ cos_out, int64_t* __restrict__ id_out, int* __restrict__ fallback) {
     __shared__ uint64_t keys[IVF_LIST_CAP];
     __shared__ uint64_t top[MAX_KP];
-    __shared__ int s_total;
+    __shared__ int hist[256];
+    __shared__ int scratch[4];
     const int q = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) s_total = 0;
-    __syncthreads();
-    for (int p = tid; p < nprobe; p += SEL_THREADS) {
-        const int64_t L = probes[(size_t)q * nprobe + p];
-        if (L >= 0) atomicAdd(&s_total, (int)(offsets[L + 1] - offsets[L]));
-    }
-    __syncthreads();
-    const int n = cnt[q];
-    if (n > IVF_LIST_CAP || n < min(kp, s_total)) {
+    const int n = cnt[q], total = totals[q];                  // (total: rows in the query's probed lists, from ivf_threshold_kernel)
+    if (n > IVF_LIST_CAP || n < min(kp, total)) {
         if (tid == 0) atomicExch(fallback, 1);
         return;
     }
     for (int i = tid; i < n; i += SEL_THREADS) keys[i] = list[(size_t)q * IVF_LIST_CAP + i];
+    if (tid == 0) scratch[2] = 0;
     __syncthreads();
     const int m = min(n, kp);
-    for (int i = tid; i < n; i += SEL_THREADS) {
-        const uint64_t ki = keys[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += keys[j] > ki ? 1 : 0;
-        if (rank < kp) top[rank] = ki;
-    }
-    __syncthreads();
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        const float4* qv = reinterpret_cast<const float4*>(qn + (size_t)q * K);
-        const int nvec = K >> 2;
-        for (int e = wave; e < m; e += SEL_WAVES) {
-            const uint32_t row = key_row(top[e]);
-            const float4* rv = reinterpret_cast<const float4*>(master + (size_t)row * K);
-            float sc = 0.f;
-            for (int v4 = lane; v4 < nvec; v4 += 64) {
-                const float4 a = rv[v4], b = qv[v4];
-                sc = fmaf(a.x, b.x, sc); sc = fmaf(a.y, b.y, sc); sc = fmaf(a.z, b.z, sc); sc = fmaf(a.w, b.w, sc);
+    // The kp best keys by byte-wise radix select (r04c; rank counting before: n^2 / 1,024 LDS reads per thread -- timing builds without
+    // it: 49 -> 8 us for one query, 154 -> 47 us at batch 1024, profiles/r04_configs/ivf_select_list_ablation.log).  Keys are unique
+    // (score | ~row), so the pass after which the located bin holds exactly the keys still wanted ends the search: three or four
+    // passes of the eight on scores that differ.
+    uint64_t T = 0;
+    if (n > kp) {
+        uint64_t prefix = 0;
+        int remaining = kp;
+        for (int byte = 7; byte >= 0; --byte) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const int shift = byte * 8;
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const uint64_t key = keys[i];
+                if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
             }
-            sc = wave_sum(sc) + 0.0f;
-            if (lane == 0) keys[e] = make_key(sc, row);          // (keys[] is free: the estimates have been ranked)
+            __syncthreads();
+            {
+                int hb, hr;
+                hist_locate(hist, remaining, hb, hr);
+                if (tid == 0) { scratch[0] = hb < 0 ? 0 : hb; scratch[1] = hr; scratch[3] = hb < 0 ? 0 : hist[hb]; }
+            }
+            __syncthreads();
+            prefix |= ((uint64_t)scratch[0] << shift);
+            remaining = scratch[1];
+            const bool whole_bin = scratch[3] == remaining;   // every key of the bin is wanted: keys >= prefix (lower bytes 0) are the kp best
+            __syncthreads();
+            if (whole_bin) break;
+        }
+        T = prefix;
+    }
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const uint64_t key = keys[i];
+        if (key >= T) {
+            const int slot = atomicAdd(&scratch[2], 1);
+            if (slot < MAX_KP) top[slot] = key;
         }
     }
+    __syncthreads();
+    rescore_top(top, keys, m, master, qn + (size_t)q * K, K, tid);          // (keys[] is free: the kp best are in top[])
     __syncthreads();
     const int mk = min(m, k);
     for (int i = tid; i < m; i += SEL_THREADS) {
@@ -1299,7 +1371,7 @@ struct IvfState {
     int n_units4 = 0, n_units1 = 0;
     Buf unitsS, unitsR;              // collect mode: the first tile of every list (the sample) / the other tiles in runs of <= 4
     int n_unitsS = 0, n_unitsR = 0;
-    Buf cthr, ccnt, clist, cflag;    // collect mode, per search: thresholds [B], list lengths [B], lists [B, IVF_LIST_CAP], fallback flag
+    Buf cthr, ccnt, clist;           // collect mode, per search: thresholds [B], list lengths [B], lists [B, IVF_LIST_CAP]
     Buf qn, qb, qd, cent_bf16, cscores, probes_cos, probes_ids, lcount, lq, pair_scores, tmp_ids, tmp_cos, sums;
     std::vector<int64_t> h_offsets;
 };
@@ -1470,6 +1542,10 @@ static int ivf_build_lists(sqe_index* base, IvfState* st, hipStream_t s) {
             if (nt > 0) uS.push_back(make_int4(i, 0, 1, 0));
             split(uR, 1);
         }
+        // the unit queue hands units out in table order: longest first, so that the launch ends on its shortest units
+        auto longer = [](const int4& a, const int4& b) { return a.z > b.z; };
+        std::stable_sort(u4.begin(), u4.end(), longer);
+        std::stable_sort(uR.begin(), uR.end(), longer);
         st->n_units4 = (int)u4.size(); st->n_units1 = (int)u1.size(); st->n_unitsS = (int)uS.size(); st->n_unitsR = (int)uR.size();
         SQE_TRY(st->units4.ensure(std::max<size_t>(1, u4.size()) * sizeof(int4)));
         SQE_TRY(st->units1.ensure(std::max<size_t>(1, u1.size()) * sizeof(int4)));
@@ -1566,13 +1642,13 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     SQE_TRY(st->qb.ensure((size_t)(B + LS_Q) * pitch));
     SQE_TRY(st->probes_cos.ensure((size_t)B * nprobe * 4));
     SQE_TRY(st->probes_ids.ensure((size_t)B * nprobe * 8));
-    SQE_TRY(st->lcount.ensure((size_t)nlist * 4));
+    SQE_TRY(st->lcount.ensure((size_t)(nlist + 4) * 4));      // (+ 4 ints behind the list counts: the collect mode's flag and unit counters)
     SQE_TRY(st->lq.ensure((size_t)nlist * B * 4));
     SQE_TRY(st->pair_scores.ensure((size_t)B * per_query));
     SQE_TRY(launch_normalize_rows(q_dev, B, dim, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
     // S5: coarse quantise
     SQE_TRY(ivf_coarse_topk(base, st, q_dev, B, nprobe, st->probes_ids.as<int64_t>(), st->probes_cos.as<float>(), s));
-    SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)nlist * 4, s));
+    SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)(nlist + 4) * 4, s));
     hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
                        st->lcount.as<int>(), st->lq.as<int>(), B);
     // S6: list scan
@@ -1630,27 +1706,26 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                 // the keys at or above them -> the lists are ranked.  Any query whose list cannot answer sets the flag, and the two gated
                 // launches at the end redo the batch through the strips (they return at once otherwise).
                 SQE_TRY(st->cthr.ensure((size_t)B * 4));
-                SQE_TRY(st->ccnt.ensure((size_t)B * 4));
+                SQE_TRY(st->ccnt.ensure((size_t)B * 8));      // (list lengths [B], rows in the probed lists [B])
                 SQE_TRY(st->clist.ensure((size_t)B * IVF_LIST_CAP * 8));
-                SQE_TRY(st->cflag.ensure(16));
-                SQE_HIP(hipMemsetAsync(st->cflag.p, 0, 16, s));
-                launch_strips(st->unitsS, st->n_unitsS, nullptr, st->cflag.as<int>() + 1);      // (cflag: [0] fallback flag, [1..3] unit counters)
-                hipLaunchKernelGGL(ivf_threshold_kernel, dim3(B), dim3(256), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
+                int* cflag = st->lcount.as<int>() + nlist;      // [0] fallback flag, [1..3] unit counters: zeroed with the list counts above
+                launch_strips(st->unitsS, st->n_unitsS, nullptr, cflag + 1);
+                hipLaunchKernelGGL(ivf_threshold_kernel, dim3(B), dim3(THR_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                                    st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, kp, st->cthr.as<float>(), st->ccnt.as<int>(),
                                    st->clist.as<uint64_t>());
                 StCollect col{st->cthr.as<float>(), st->ccnt.as<int>(), st->clist.as<uint64_t>(), IVF_LIST_CAP, st->order.as<int>()};
-                int* cqueue = (no_queue || st->n_unitsR <= persistent) ? nullptr : st->cflag.as<int>() + 2;
+                int* cqueue = (no_queue || st->n_unitsR <= persistent) ? nullptr : cflag + 2;
                 hipLaunchKernelGGL(collect, dim3(cqueue ? persistent : st->n_unitsR), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride,
                                    st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->unitsR.as<int4>(),
                                    st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                                    st->pair_scores.as<float>(), col, (const int*)nullptr, cqueue, st->n_unitsR);
-                hipLaunchKernelGGL(ivf_select_list_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
-                                   st->ccnt.as<int>(), st->clist.as<uint64_t>(), nprobe, k, kp, base->id_base, base->master, st->qn.as<float>(), dim,
-                                   cos_out, id_out, st->cflag.as<int>());
-                launch_strips(st->units4, st->n_units4, st->cflag.as<int>(), st->cflag.as<int>() + 3);
+                hipLaunchKernelGGL(ivf_select_list_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->ccnt.as<int>(), st->ccnt.as<int>() + B,
+                                   st->clist.as<uint64_t>(), k, kp, base->id_base, base->master, st->qn.as<float>(), dim,
+                                   cos_out, id_out, cflag);
+                launch_strips(st->units4, st->n_units4, cflag, cflag + 3);
                 hipLaunchKernelGGL(ivf_select_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->probes_ids.as<int64_t>(), st->offsets.as<int64_t>(),
                                    st->order.as<int>(), st->pair_scores.as<float>(), nprobe, max_len, k, kp, base->id_base,
-                                   base->master, st->qn.as<float>(), dim, cos_out, id_out, st->cflag.as<int>());
+                                   base->master, st->qn.as<float>(), dim, cos_out, id_out, cflag);
                 SQE_HIP(hipGetLastError());
                 return SQE_OK;
             }

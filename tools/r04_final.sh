@@ -2,8 +2,9 @@
 # usage (GPU box, repo root): tools/r04_final.sh <part>  -> gpurun_out/r04f/*
 #   1  the GPU suite + the default bench line + the same bench under rocprofv3 (kernel stats)
 #   2  PMC passes (HBM traffic, SQ counters) of both first passes at batch 1024 -> pmc_traffic_{int8,bf16}.json (scan sources hashed)
-#   3  the other configs: encode / e2e, encoder at the reference's shapes (+ rocprofv3 summary of 64 x 512), IVF sweep + its rocprofv3
-#      kernel trace and FETCH / WRITE passes, hard data, cache, ingest, single-query latency, group host cost
+#   3  the other configs: encode / e2e, encoder at the reference's shapes (+ rocprofv3 summary of 64 x 512, kernel-by-kernel trace of one
+#      1 x 16-token forward), hard data, cache, ingest, single-query latency, group host cost
+#   5  IVF: its tests, the batch sweep under rocprofv3 (kernel trace), FETCH / WRITE passes
 #   4  batch sweep of the flat search in both scan modes, shard sizes, launch fixed cost
 export TMPDIR=/tmp
 out=gpurun_out/r04f
@@ -32,6 +33,14 @@ elif [ "$part" = "3" ]; then
   # one 1 x 16-token forward, kernel by kernel (execution time against launch gaps)
   rocprofv3 --kernel-trace --output-format csv -d $out/b1_prof -- python3 tools/latency_b1.py > /dev/null 2> $out/b1_prof.err
   python3 tools/trace_forward.py $out/b1_prof 10 | tee $out/enc_1x16_forward_trace.txt; rm -rf $out/b1_prof
+  python bench_configs.py --mode hard 2> $out/hard.err | tail -1 > $out/cfg_hard.json; echo "== hard done"; cat $out/cfg_hard.json
+  python bench_configs.py --mode cache 2> $out/cache.err | tail -1 > $out/cfg_cache.json; echo "== cache done"
+  python bench_configs.py --mode ingest 2> $out/ingest.err | tail -1 > $out/cfg_ingest.json; echo "== ingest done"
+  python tools/group_host_cost.py --scan-mode int8 > $out/group_host_cost.jsonl 2> $out/group_host_cost.err; cat $out/group_host_cost.jsonl
+elif [ "$part" = "5" ]; then
+  { timeout -k 10 500 python -m pytest tests/test_ivf_gpu.py tests/test_config5_gpu.py -m gpu -q -x > $out/tests_ivf.log 2>&1 || [ $? -eq 1 ]; } || exit 1
+  tail -3 $out/tests_ivf.log
+  grep -q passed $out/tests_ivf.log && ! grep -q failed $out/tests_ivf.log || { tail -60 $out/tests_ivf.log; exit 1; }
   # IVF: the sweep, then its kernel trace (longest dispatch of a kernel = the batch-1024 search, shortest list scan = batch 1) and HBM traffic
   tools/r04_ivf_ab.sh $out ""
   for pass in FETCH_SIZE WRITE_SIZE; do
@@ -53,10 +62,6 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print(f"{c} {k}: largest dispatch {v * 1024 * (2 if c == 'FETCH_SIZE' else 1) / 1e9:.3f} GB")
 PY
   rm -rf $out/ivf_pmc_FETCH_SIZE $out/ivf_pmc_WRITE_SIZE
-  python bench_configs.py --mode hard 2> $out/hard.err | tail -1 > $out/cfg_hard.json; echo "== hard done"; cat $out/cfg_hard.json
-  python bench_configs.py --mode cache 2> $out/cache.err | tail -1 > $out/cfg_cache.json; echo "== cache done"
-  python bench_configs.py --mode ingest 2> $out/ingest.err | tail -1 > $out/cfg_ingest.json; echo "== ingest done"
-  python tools/group_host_cost.py --scan-mode int8 > $out/group_host_cost.jsonl 2> $out/group_host_cost.err; cat $out/group_host_cost.jsonl
 else
   for mode in int8 bf16; do
     for b in 1 8 64 128 256 512 1024 2048; do
