@@ -1293,6 +1293,19 @@ __device__ __forceinline__ float4 ln_load(const float* row, int i, int nsplit, s
                            bf16_to_f32((bf16_t)(w.y & 0xffff)), bf16_to_f32((bf16_t)(w.y >> 16)));
     }
     float4 v = *reinterpret_cast<const float4*>(row + i);
+    if (nsplit == 1) return v;
+    if (nsplit <= 4) {
+        // (r04c) up to four partial sums, their loads issued together: a loop of `nsplit` trips is `nsplit` dependent round trips (the
+        // LayerNorm of 16 tokens took 6.8 us, profiles/r04_configs/enc_1x16_forward_trace.txt).  A partial sum that does not exist is
+        // read from partial sum 0 (a hit) and not added: no branch around the loads, the same additions in the same order.
+        float4 w[3];
+#pragma unroll
+        for (int s = 1; s < 4; ++s) w[s - 1] = *reinterpret_cast<const float4*>(row + (size_t)(s < nsplit ? s : 0) * stride + i);
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+            if (s < nsplit) { v.x += w[s - 1].x; v.y += w[s - 1].y; v.z += w[s - 1].z; v.w += w[s - 1].w; }
+        return v;
+    }
     for (int s = 1; s < nsplit; ++s) {
         const float4 w = *reinterpret_cast<const float4*>(row + (size_t)s * stride + i);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
