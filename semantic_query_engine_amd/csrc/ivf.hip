@@ -721,7 +721,8 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
                                                                         const int64_t* __restrict__ offsets, const int* __restrict__ lcount,
                                                                         const int* __restrict__ lq, int cap, int nprobe, int K, int max_len,
                                                                         float* __restrict__ pair_scores, StCollect col, const int* __restrict__ gate,
-                                                                        int* __restrict__ queue, int n_units) {
+                                                                        int* __restrict__ queue, int n_units,
+                                                                        const int64_t* __restrict__ pair_probes, int pair_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_next;
     if (gate && *gate == 0) return;                            // (the strip-mode fallback of a collect search: only if some query asked for it)
@@ -746,9 +747,23 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
     unsigned char* cbuf_col = reinterpret_cast<unsigned char*>(cbuf_key + ST_CBUF);
     int* cbuf_n = reinterpret_cast<int*>(cbuf_col + ST_CBUF);
     float* sthr = reinterpret_cast<float*>(cbuf_n + 4);        // [ST_Q]
-    const int4 u = units[unit];
+    // pair_probes != null (a handful of queries, no queue): the grid is (query, probe) pair x tile of its list -- a few hundred workgroups
+    // that all have work.  The unit table of single tiles it replaces is ~40 k workgroups for 10 M rows, of which one query uses 320:
+    // handing the others their table entry and list count took most of the 72 us this launch lasted (r04c).
+    int4 u;
+    int m;
+    if (pair_probes) {
+        const int pair = unit / pair_tiles;
+        const int64_t Lp = pair_probes[pair];
+        if (Lp < 0) return;
+        u = make_int4((int)Lp, unit - pair * pair_tiles, 1, pair);
+        if (u.y >= (int)(tile_off[Lp + 1] - tile_off[Lp])) return;
+        m = 1;
+    } else {
+        u = units[unit];
+        m = min(lcount[u.x], cap);
+    }
     const int L = u.x, ntiles = u.z;
-    const int m = min(lcount[L], cap);
     if (m == 0) {                                              // nobody probes this list
         if (!queue) return;
         continue;
@@ -781,7 +796,7 @@ __global__ __launch_bounds__(ST_THREADS) void ivf_list_stream_i8_kernel(const in
         const int gq = min(ST_Q, m - g0);
         __syncthreads();                                       // the previous pass is done with the query block
         if (tid < ST_Q) {
-            const int pr = lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
+            const int pr = pair_probes ? u.w : lq[(size_t)L * cap + g0 + min(tid, gq - 1)];
             spair[tid] = pr;
             sqscale[tid] = unit2 * (float)sqi[pr / nprobe];
             if (COLLECT) sthr[tid] = tid < gq ? col.thr[pr / nprobe] : INFINITY;
@@ -1128,11 +1143,20 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
         for (int p = wave4; p < nprobe; p += SEL_WAVES) {
             const int len = s_len[p];
             const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;
-            for (int i = lane64 * stride + (p % stride); i < len; i += 64 * stride) {
-                const float sc = strip[i];
-                if (sc != sc) continue;
-                const int slot = atomicAdd(&scratch[0], 1);
-                if (slot < SAMPLE_CAP) sample[slot] = f32_orderable(sc + 0.0f);
+            // (r04c: four loads of a lane in flight; one at a time the strip came in as a chain of dependent round trips)
+            for (int i0 = lane64 * stride + (p % stride); i0 < len; i0 += 4 * 64 * stride) {
+                float sc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 64 * stride;
+                    sc[u] = i < len ? strip[i] : __builtin_nanf("");
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (sc[u] != sc[u]) continue;
+                    const int slot = atomicAdd(&scratch[0], 1);
+                    if (slot < SAMPLE_CAP) sample[slot] = f32_orderable(sc[u] + 0.0f);
+                }
             }
         }
         __syncthreads();
@@ -1169,14 +1193,24 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
             const int len = s_len[p];
             const int64_t off = s_off[p];
             const float* strip = pair_scores + ((size_t)q * nprobe + p) * max_len;   // (16-byte aligned: max_len is a multiple of 4)
-            for (int i = lane64 * 4; i < len; i += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(strip + i);           // (strips are padded to 4 floats)
+            for (int i0 = lane64 * 4; i0 < len; i0 += 4 * 256) {         // (four 16-byte loads of a lane in flight)
+                f32x4 v4[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sc = v[e];
-                    if (i + e < len && sc == sc && f32_orderable(sc + 0.0f) >= thr) {
-                        const int slot = atomicAdd(&scratch[2], 1);
-                        if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)order[off + i + e]);
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+                    const f32x4 nan4 = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                    v4[u] = i < len ? *reinterpret_cast<const f32x4*>(strip + i) : nan4;           // (strips are padded to 4 floats)
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sc = v4[u][e];
+                        if (i + e < len && sc == sc && f32_orderable(sc + 0.0f) >= thr) {
+                            const int slot = atomicAdd(&scratch[2], 1);
+                            if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)order[off + i + e]);
+                        }
                     }
                 }
             }
@@ -1694,12 +1728,12 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
             SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(collect), (int)st_lds));
             static const bool no_queue = [] { const char* e = knob_env("SQE_IVF_QUEUE"); return e && e[0] == '0'; }();   // knobs build: one workgroup per unit, for A/B
             const int persistent = 2 * base->ctx->cu_count;                  // two workgroups per CU
-            auto launch_strips = [&](const Buf& units, int n_units, const int* gate, int* queue) {
+            auto launch_strips = [&](const Buf& units, int n_units, const int* gate, int* queue, const int64_t* pair_probes = nullptr, int pair_tiles = 0) {
                 if (no_queue || n_units <= persistent) queue = nullptr;
                 hipLaunchKernelGGL(strips, dim3(queue ? persistent : n_units), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride,
                                    st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, units.as<int4>(),
                                    st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
-                                   st->pair_scores.as<float>(), StCollect{}, gate, queue, n_units);
+                                   st->pair_scores.as<float>(), StCollect{}, gate, queue, n_units, pair_probes, pair_tiles);
             };
             if (!few && !strips_only && nprobe <= 32 && st->n_unitsR > 0) {
                 // ---- collect mode (r04b): sample pass over the first tile of every list -> per-query thresholds -> the other tiles keep only
@@ -1718,7 +1752,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                 hipLaunchKernelGGL(collect, dim3(cqueue ? persistent : st->n_unitsR), dim3(ST_THREADS), st_lds, s, st->i8rows.as<int8_t>(), tile_stride,
                                    st->i8sxi.as<uint32_t>(), st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), unit * unit, st->unitsR.as<int4>(),
                                    st->tile_off.as<int64_t>(), st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
-                                   st->pair_scores.as<float>(), col, (const int*)nullptr, cqueue, st->n_unitsR);
+                                   st->pair_scores.as<float>(), col, (const int*)nullptr, cqueue, st->n_unitsR, (const int64_t*)nullptr, 0);
                 hipLaunchKernelGGL(ivf_select_list_kernel, dim3(B), dim3(SEL_THREADS), 0, s, st->ccnt.as<int>(), st->ccnt.as<int>() + B,
                                    st->clist.as<uint64_t>(), k, kp, base->id_base, base->master, st->qn.as<float>(), dim,
                                    cos_out, id_out, cflag);
@@ -1729,7 +1763,16 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
                 SQE_HIP(hipGetLastError());
                 return SQE_OK;
             }
-            launch_strips(few ? st->units1 : st->units4, few ? st->n_units1 : st->n_units4, nullptr, nullptr);
+            if (few) {
+                // a handful of queries: one workgroup per (query, probe) pair and tile of its list (the lists of different queries are read
+                // separately; at most 512 pairs)
+                static const bool unit_table = [] { const char* e = knob_env("SQE_IVF_FEW_TABLE"); return e && e[0] == '1'; }();   // knobs build: the single-tile unit table, for A/B
+                const int pair_tiles = (max_len + LS_ROWS - 1) / LS_ROWS;
+                if (unit_table) launch_strips(st->units1, st->n_units1, nullptr, nullptr);
+                else launch_strips(st->units1, B * nprobe * pair_tiles, nullptr, nullptr, st->probes_ids.as<int64_t>(), pair_tiles);
+            } else {
+                launch_strips(st->units4, st->n_units4, nullptr, nullptr);
+            }
         } else {
         SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(ivf_list_scan_i8_kernel), LS_LDS_I8));
         // a handful of queries: pair mode (the kernel's comment), up to 16 workgroups per probed list
