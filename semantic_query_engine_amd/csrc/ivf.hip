@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
                         const float sc = v4[u][e];
                         if (i + e < len && sc == sc && f32_orderable(sc + 0.0f) >= thr) {
                             const int slot = atomicAdd(&scratch[2], 1);
-                            if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)order[off + i + e]);
+                            if (slot < COLLECT_CAP) coll[slot] = make_key(sc, (uint32_t)(off + i + e));      // (position in the lists, for now)
                         }
                     }
                 }
@@ -1217,6 +1217,12 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_select_kernel(const int64_t* 
         }
         __syncthreads();
         const int nc = scratch[2];
+        // positions -> row ids, all collected keys at once (r04c: looked up where a key was found, every hit of a wave was a dependent
+        // round trip of its own)
+        for (int i = tid; i < min(nc, COLLECT_CAP); i += SEL_THREADS) {
+            const uint64_t kpos = coll[i];
+            coll[i] = make_key(key_score(kpos), (uint32_t)order[key_row(kpos)]);
+        }
         __syncthreads();
         if (nc >= kp && nc <= COLLECT_CAP) {
             for (int i = tid; i < nc; i += SEL_THREADS) {
@@ -1433,7 +1439,7 @@ static int ivf_coarse_topk(sqe_index* base, IvfState* st, const float* rows_dev,
     for (int64_t off = 0; off < b; off += step) {
         const int m = (int)std::min(step, b - off);
         const int t_pad = (m + 127) / 128 * 128;
-        if (t_pad > m) SQE_HIP(hipMemsetAsync(st->qd.as<char>() + (size_t)m * dim * 2, 0, (size_t)(t_pad - m) * dim * 2, s));
+        // (rows m .. t_pad of qd keep whatever they held: the GEMM computes their scores and stores none of them)
         SQE_TRY(launch_normalize_rows(rows_dev + (size_t)off * dim, m, dim, dim, nullptr, st->qd.as<bf16_t>(), dim, nullptr, nullptr, s));
         SQE_TRY(launch_scores_gemm(st->cent_bf16.as<bf16_t>(), st->qd.as<bf16_t>(), st->cscores.as<float>(), nlist, dim, m, t_pad,
                                    ctx->cu_count, s));
@@ -1682,16 +1688,25 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     SQE_TRY(launch_normalize_rows(q_dev, B, dim, dim, st->qn.as<float>(), st->qb.as<bf16_t>(), pitch / 2, nullptr, nullptr, s));
     // S5: coarse quantise
     SQE_TRY(ivf_coarse_topk(base, st, q_dev, B, nprobe, st->probes_ids.as<int64_t>(), st->probes_cos.as<float>(), s));
-    SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)(nlist + 4) * 4, s));
-    hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
-                       st->lcount.as<int>(), st->lq.as<int>(), B);
     // S6: list scan
     static const bool fp32_lists = [] { const char* e = knob_env("SQE_IVF_FP32"); return e && e[0] == '1'; }();   // knobs build only
+    static const bool staged = [] { const char* e = knob_env("SQE_IVF_STAGED"); return e && e[0] == '1'; }();   // knobs build: the r03 kernel, for A/B
+    static const bool unit_table = [] { const char* e = knob_env("SQE_IVF_FEW_TABLE"); return e && e[0] == '1'; }();   // knobs build: the single-tile unit table for a handful of queries, for A/B
+    const size_t st_lds = (size_t)ST_Q * (dim + 128) + ST_UNIT_TILES * LS_ROWS * 4 + ST_Q * 8 + (ST_THREADS / 64) * ST_PATCH_ROWS * ST_PATCH_PITCH * 4;
+    const bool i8_lists = !fp32_lists && st->use_i8 && dim >= 256 && dim % 128 == 0 && !ivf_i8_off();
+    const bool streaming = i8_lists && !staged && dim % (64 * ST_SL) == 0 && st_lds <= 80 * 1024 && st->n_units4 > 0;      // (two workgroups per CU)
+    // a handful of queries through the streaming scan: one workgroup per (query, probe) pair and tile -- no per-list query buckets needed
+    const bool pair_grid = streaming && B * nprobe <= 512 && !unit_table;
+    if (!pair_grid) {
+        SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)(nlist + 4) * 4, s));
+        hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
+                           st->lcount.as<int>(), st->lq.as<int>(), B);
+    }
     if (fp32_lists) {
         hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(nlist), dim3(256), 0, s, base->master, st->qn.as<float>(), st->order.as<int>(),
                            st->offsets.as<int64_t>(), st->lcount.as<int>(), st->lq.as<int>(), B, nprobe, dim, max_len,
                            st->pair_scores.as<float>());
-    } else if (st->use_i8 && dim >= 256 && dim % 128 == 0 && !ivf_i8_off()) {
+    } else if (i8_lists) {
         // ---- int8 list scan: half the bytes per probed row, every list a run of whole 256-row tiles in the flat scan's tiled
         // layout (a K step of a tile is 32 contiguous KiB).  The copy is in list order, so it is rebuilt from the master whenever
         // the lists were (rows added, rows overwritten): ivf_build_lists / ivf_rows_updated reset i8_done.  ~12 ms per 10 M rows,
@@ -1716,9 +1731,7 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
         SQE_TRY(st->q8sqi.ensure((size_t)(B + LS_Q) * 4));
         SQE_TRY(launch_quantize_queries_i8(st->qn.as<float>(), B, dim, st->q8.as<int8_t>(), p8, st->q8sqi.as<uint32_t>(), nullptr, s));
         const float unit = i8_scale_unit(dim);
-        static const bool staged = [] { const char* e = knob_env("SQE_IVF_STAGED"); return e && e[0] == '1'; }();   // knobs build: the r03 kernel, for A/B
-        const size_t st_lds = (size_t)ST_Q * (dim + 128) + ST_UNIT_TILES * LS_ROWS * 4 + ST_Q * 8 + (ST_THREADS / 64) * ST_PATCH_ROWS * ST_PATCH_PITCH * 4;
-        if (!staged && dim % (64 * ST_SL) == 0 && st_lds <= 80 * 1024 && st->n_units4 > 0) {      // (two workgroups per CU)
+        if (streaming) {
             // streaming form: one workgroup per unit of <= 4 tiles (single tiles when only a handful of lists are probed)
             const bool few = B * nprobe <= 512;
             static const bool strips_only = [] { const char* e = knob_env("SQE_IVF_STRIPS"); return e && e[0] == '1'; }();   // knobs build: r04a's form, for A/B
@@ -1766,9 +1779,8 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
             if (few) {
                 // a handful of queries: one workgroup per (query, probe) pair and tile of its list (the lists of different queries are read
                 // separately; at most 512 pairs)
-                static const bool unit_table = [] { const char* e = knob_env("SQE_IVF_FEW_TABLE"); return e && e[0] == '1'; }();   // knobs build: the single-tile unit table, for A/B
                 const int pair_tiles = (max_len + LS_ROWS - 1) / LS_ROWS;
-                if (unit_table) launch_strips(st->units1, st->n_units1, nullptr, nullptr);
+                if (!pair_grid) launch_strips(st->units1, st->n_units1, nullptr, nullptr);
                 else launch_strips(st->units1, B * nprobe * pair_tiles, nullptr, nullptr, st->probes_ids.as<int64_t>(), pair_tiles);
             } else {
                 launch_strips(st->units4, st->n_units4, nullptr, nullptr);
