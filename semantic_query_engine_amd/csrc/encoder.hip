@@ -148,15 +148,6 @@ struct GemmArgs {
     int xcd_patches;      // gemm_ring_kernel: XCD-aware tile walk (0: linear)
     int pp_stagger;       // gemm_pp_kernel: half of a group's waves read their operands before they issue their DMA pieces
     int pp_dbg;           // gemm_pp_kernel, knobs build, timing only: 2 = no stores (results wrong), 4 = phase stamps (STAMPS build)
-    // gemm_skinny_kernel<EPI, true> (r04c): X = LayerNorm(sum of the ln_nsplit partial sums in ln_pre), computed by EVERY workgroup into
-    // LDS behind its weight loads; workgroup 0 also writes the rows to ln_x (the residual of a later GEMM).  K = the hidden size.
-    const float* ln_pre = nullptr;
-    int ln_nsplit = 0;
-    size_t ln_stride = 0;           // floats between partial sums
-    const float* ln_g = nullptr;    // gamma, beta [K]
-    const float* ln_b = nullptr;
-    float ln_eps = 0.f;
-    bf16_t* ln_x = nullptr;         // [T, K]
 };
 
 // Block tile: (2*FM*16) output features x (4*FN*16) tokens, 8 waves as 2 (features) x 4 (tokens).
@@ -1157,15 +1148,9 @@ int launch_gemm_ring(const GemmArgs& a, int t_pad, int cu_count, size_t split_st
 // k + 32 i + 8 (lane >> 4): 64 contiguous bytes per row per instruction; X rows the same way, L2-resident), no
 // LDS staging, the four partial sums meet in LDS and wave j finishes token group j.  N / 16 workgroups (x the
 // split-K factor for the two N = hidden GEMMs, whose partial sums the LayerNorm kernels already add).
-__device__ __forceinline__ bool ln_row_regs(const float* row, int H, int lane, float eps, int nsplit, size_t stride, float4 (&v)[4], float& mean,
-                                            float& rstd);
-// LNX (r04c): the X operand is the LayerNorm of the previous GEMM's partial sums, done HERE -- the 47 LayerNorm launches of a forward
-// of a handful of tokens (7 us each with their gap, profiles/r04_configs/enc_1x16_forward_trace.txt) are gone.  Every workgroup
-// normalises all T rows (<= 64 x 1024 values, L2-resident) into LDS while its weight fragments, issued first, are on their way from HBM.
-template <int EPI, bool LNX = false>
+template <int EPI>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     __shared__ float4 red[4][4][64];          // [K-split wave][token group][lane]
-    extern __shared__ __attribute__((aligned(16))) char skinny_dyn[];      // LNX: bf16 [16 nt][K + 8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int groups = p.N >> 4;
@@ -1184,8 +1169,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // two 128-wide steps per pass, the loads of both issued before the first MFMA (kwave is 128 or 256 for the
     // BERT-large shapes: one pass, one memory round trip)
-    const int xp = p.K + 8;                   // LNX: LDS pitch of a row, elements
-    bf16_t* xs = reinterpret_cast<bf16_t*>(skinny_dyn);
     for (int k = 0; k < kwave; k += 256) {
         bf16x8 a[2][4], b[2][4][4];
         const bool two = k + 128 < kwave;
@@ -1194,48 +1177,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
             if (h == 0 || two) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[h][i] = *reinterpret_cast<const bf16x8*>(wrow + k + h * 128 + i * 32);
-            }
-        if (LNX && k == 0) {
-            // (the launcher gives this form one pass: kwave = 256) rows wave, wave + 4, ... -- two at a time
-            const int H = p.K, nit = H >> 8;
-            for (int r0 = wave; r0 < p.T; r0 += 8) {
-                const int rb = r0 + 4 < p.T ? r0 + 4 : r0;
-                float4 va[4], vb[4];
-                float ma, qa, mb, qb;
-                (void)ln_row_regs(p.ln_pre + (size_t)r0 * H, H, lane, p.ln_eps, p.ln_nsplit, p.ln_stride, va, ma, qa);
-                (void)ln_row_regs(p.ln_pre + (size_t)rb * H, H, lane, p.ln_eps, p.ln_nsplit, p.ln_stride, vb, mb, qb);
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    if (it < nit) {
-                        const int i = lane * 4 + it * 256;
-                        const float4 gg = *reinterpret_cast<const float4*>(p.ln_g + i);
-                        const float4 bb = *reinterpret_cast<const float4*>(p.ln_b + i);
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            if (hh == 1 && rb == r0) break;
-                            const float4 v = hh ? vb[it] : va[it];
-                            const float mean = hh ? mb : ma, rstd = hh ? qb : qa;
-                            const int row = hh ? rb : r0;
-                            uint2 w;                                       // (layernorm_kernel's expression: the same bits)
-                            w.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
-                            w.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
-                            *reinterpret_cast<uint2*>(xs + (size_t)row * xp + i) = w;
-                            if (blockIdx.x == 0) *reinterpret_cast<uint2*>(p.ln_x + (size_t)row * H + i) = w;
-                        }
-                    }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (h == 0 || two) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < nt) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            b[h][j][i] = LNX ? *reinterpret_cast<const bf16x8*>(xs + (size_t)(j * 16 + r) * xp + kbeg + c * 8 + k + h * 128 + i * 32)
-                                             : *reinterpret_cast<const bf16x8*>(xrow + j * xgroup + k + h * 128 + i * 32);
+                            b[h][j][i] = *reinterpret_cast<const bf16x8*>(xrow + j * xgroup + k + h * 128 + i * 32);
                     }
             }
 #pragma unroll
@@ -1296,15 +1243,7 @@ int launch_gemm_skinny(const GemmArgs& a, int cu_count, size_t split_stride, int
     p.splits = splits;
     p.split_stride = split_stride;
     if (splits_out) *splits_out = splits;
-    if (a.ln_pre) {                            // X = LayerNorm(ln_pre), done by the kernel (encode_enqueue asks for it with K = 1024 only)
-        if (EPI == EPI_RESID || a.K != 1024 || splits != 1) return fail(SQE_ERR_STATE, "encoder gemm: LayerNorm on read needs K = 1024, no split");
-        auto kern = gemm_skinny_kernel<EPI, true>;
-        const int lds = ((a.T + 15) / 16) * 16 * (a.K + 8) * 2;
-        SQE_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
-        hipLaunchKernelGGL(kern, dim3(a.N / 16), dim3(256), lds, stream, p);
-    } else {
-        hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3((a.N / 16) * splits), dim3(256), 0, stream, p);
-    }
+    hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3((a.N / 16) * splits), dim3(256), 0, stream, p);
     SQE_HIP(hipGetLastError());
     return SQE_OK;
 }
@@ -1312,18 +1251,15 @@ int launch_gemm_skinny(const GemmArgs& a, int cu_count, size_t split_stride, int
 // 256x256 tiles when there are enough tokens to fill the chip with them, the 128x128 ring kernel otherwise.
 // *splits_out = number of fp32 partial sums written (EPI_RESID), `split_stride` floats apart; 0 = the output is
 // ONE bf16 row per token (the persistent kernel).
-// (the shapes gemm_skinny_kernel takes: encode_enqueue asks before it hands a GEMM the LayerNorm in front of it, GemmArgs::ln_pre)
-inline bool gemm_is_skinny(int T, int K) {
-    static const bool off = [] { const char* e = knob_env("SQE_ENC_SKINNY"); return e && e[0] == '0'; }();
-    return T <= 64 && K % 512 == 0 && !off;
-}
 template <int EPI>
 int launch_gemm(const GemmArgs& a, int t_pad, int cu_count, hipStream_t stream, size_t split_stride = 0,
                 int* splits_out = nullptr) {
     if (a.N % 128 != 0 || a.K % 64 != 0) return fail(SQE_ERR_INVALID, "encoder gemm: N % 128 or K % 64");
     if (splits_out) *splits_out = 1;
-    if (EPI != EPI_F32 && gemm_is_skinny(a.T, a.K)) return launch_gemm_skinny<EPI>(a, cu_count, split_stride, splits_out, stream);
-    if (a.ln_pre) return fail(SQE_ERR_STATE, "encoder gemm: LayerNorm on read asked of a kernel that has none");
+    if (EPI != EPI_F32 && a.T <= 64 && a.K % 512 == 0) {
+        static const bool off = [] { const char* e = knob_env("SQE_ENC_SKINNY"); return e && e[0] == '0'; }();
+        if (!off) return launch_gemm_skinny<EPI>(a, cu_count, split_stride, splits_out, stream);
+    }
     const bool big = a.N % 256 == 0 && t_pad % 256 == 0 && (int64_t)(a.N / 256) * (t_pad / 256) >= cu_count;
     if (big) {
         static const bool old_form = [] { const char* e = knob_env("SQE_ENC_GEMM_V0"); return e && e[0] == '1'; }();
@@ -2049,11 +1985,6 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
                        enc->type.as<bf16_t>(), enc->emb_g.as<float>(), enc->emb_b.as<float>(), enc->pre.as<float>(),
                        enc->x.as<bf16_t>(), T, S, H, c.vocab_size, c.ln_eps);
     SQE_HIP(hipGetLastError());
-    // a handful of tokens: no LayerNorm launches -- the GEMM that consumes a LayerNorm's rows (FFN-up behind LN1, the next layer's QKV
-    // behind LN2) normalises them itself (gemm_skinny_kernel<EPI, true>); only the last layer's pooled LayerNorm stays a kernel
-    static const bool no_fold = [] { const char* e = knob_env("SQE_ENC_LN_FOLD"); return e && e[0] == '0'; }();   // knobs build: separate LayerNorm launches, for A/B
-    const bool ln_fold = !no_fold && H == 1024 && gemm_is_skinny(T, H) && gemm_is_skinny(T, I);
-    int ns_prev = 1;                                               // partial sums of the previous layer's FFN-down (ln_fold)
     const int att_qb = S >= 256 ? 256 : S >= 128 ? 128 : 64;      // query rows per attention workgroup
     const int qblocks = (S + att_qb - 1) / att_qb;
     for (int l = 0; l < c.layers; ++l) {
@@ -2062,13 +1993,7 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
         a.T = T; a.resid = nullptr; a.n_tiles = 0;
         // E2: QKV projection
         a.W = L.w_qkv.as<bf16_t>(); a.X = enc->x.as<bf16_t>(); a.bias = L.b_qkv.as<float>(); a.out = enc->qkv.p; a.N = 3 * H; a.K = H;
-        if (ln_fold && l > 0) {                                    // x = LN2 of the previous layer, from its FFN-down's partial sums
-            sqe_layer& P = *enc->layers[l - 1];
-            a.ln_pre = enc->pre.as<float>(); a.ln_nsplit = ns_prev; a.ln_stride = pstride;
-            a.ln_g = P.ln2_g.as<float>(); a.ln_b = P.ln2_b.as<float>(); a.ln_eps = c.ln_eps; a.ln_x = enc->x.as<bf16_t>();
-        }
         SQE_TRY(launch_gemm<EPI_BIAS>(a, t_pad, cus, st));
-        a.ln_pre = nullptr;
         // E3: attention
         static const int att_form = [] { const char* e = knob_env("SQE_ATT_FORM"); return e ? atoi(e) : 0; }();   // knobs build: A/B
         const bf16_t* qkvp = enc->qkv.as<bf16_t>();
@@ -2092,27 +2017,19 @@ static int encode_enqueue(sqe_encoder* enc, const int32_t* ids_dev, const int32_
         a.out = enc->pre.p; a.N = H; a.K = H;
         int ns = 1;
         SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st, pstride, &ns));
-        if (!ln_fold)
-            hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln1_g.as<float>(),
-                               L.ln1_b.as<float>(), enc->x1.as<bf16_t>(), T, H, c.ln_eps, ns, pstride);
+        hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln1_g.as<float>(),
+                           L.ln1_b.as<float>(), enc->x1.as<bf16_t>(), T, H, c.ln_eps, ns, pstride);
         // E5: FFN up + GELU
         a.W = L.w_1.as<bf16_t>(); a.X = enc->x1.as<bf16_t>(); a.bias = L.b_1.as<float>(); a.resid = nullptr;
         a.out = enc->hbuf.p; a.N = I; a.K = H;
-        if (ln_fold) {                                             // x1 = LN1, from the out-projection's partial sums
-            a.ln_pre = enc->pre.as<float>(); a.ln_nsplit = ns; a.ln_stride = pstride;
-            a.ln_g = L.ln1_g.as<float>(); a.ln_b = L.ln1_b.as<float>(); a.ln_eps = c.ln_eps; a.ln_x = enc->x1.as<bf16_t>();
-        }
         SQE_TRY(launch_gemm<EPI_GELU>(a, t_pad, cus, st));
-        a.ln_pre = nullptr;
         // E6: FFN down + residual, LayerNorm (the last layer's LayerNorm is done by the pooling kernel in fp32)
         a.W = L.w_2.as<bf16_t>(); a.X = enc->hbuf.as<bf16_t>(); a.bias = L.b_2.as<float>(); a.resid = enc->x1.as<bf16_t>();
         a.out = enc->pre.p; a.N = H; a.K = I;
         SQE_TRY(launch_gemm<EPI_RESID>(a, t_pad, cus, st, pstride, &ns));
-        ns_prev = ns;
         if (l + 1 < c.layers) {
-            if (!ln_fold)
-                hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
-                                   L.ln2_b.as<float>(), enc->x.as<bf16_t>(), T, H, c.ln_eps, ns, pstride);
+            hipLaunchKernelGGL(layernorm_kernel, dim3(rows4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
+                               L.ln2_b.as<float>(), enc->x.as<bf16_t>(), T, H, c.ln_eps, ns, pstride);
         } else {
             hipLaunchKernelGGL(pool_ln_kernel, dim3((B + 3) / 4), dim3(256), 0, st, enc->pre.as<float>(), L.ln2_g.as<float>(),
                                L.ln2_b.as<float>(), out_dev, B, S, H, c.ln_eps, ns, pstride);
