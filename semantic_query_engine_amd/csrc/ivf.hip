@@ -1696,7 +1696,9 @@ int ivf_search(sqe_index* base, IvfState* st, const float* q_dev, int B, int k, 
     const bool i8_lists = !fp32_lists && st->use_i8 && dim >= 256 && dim % 128 == 0 && !ivf_i8_off();
     const bool streaming = i8_lists && !staged && dim % (64 * ST_SL) == 0 && st_lds <= 80 * 1024 && st->n_units4 > 0;      // (two workgroups per CU)
     // a handful of queries through the streaming scan: one workgroup per (query, probe) pair and tile -- no per-list query buckets needed
-    const bool pair_grid = streaming && B * nprobe <= 512 && !unit_table;
+    // (... unless one list is so long that a grid of pairs x tiles-of-the-longest-list would be mostly empty: the unit table then)
+    const bool pair_grid = streaming && B * nprobe <= 512 && !unit_table &&
+                           (int64_t)B * nprobe * ((max_len + LS_ROWS - 1) / LS_ROWS) <= std::max<int64_t>(8192, 2 * (int64_t)st->n_units1);
     if (!pair_grid) {
         SQE_HIP(hipMemsetAsync(st->lcount.p, 0, (size_t)(nlist + 4) * 4, s));
         hipLaunchKernelGGL(ivf_bucket_kernel, dim3((B * nprobe + 255) / 256), dim3(256), 0, s, st->probes_ids.as<int64_t>(), B, nprobe,
