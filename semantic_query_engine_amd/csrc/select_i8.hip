@@ -50,18 +50,6 @@ __device__ __forceinline__ void rescore_range(const uint64_t* in, uint64_t* out,
         const float4* a0 = reinterpret_cast<const float4*>(master + (size_t)r0 * K);
         const float4* a1 = reinterpret_cast<const float4*>(master + (size_t)r1 * K);
         float s0 = 0.f, s1 = 0.f;
-        if (nvec == 256) {
-            // (r04c) K = 1024: a lane's four steps unrolled, the loads of both rows issued before the first sum -- the loop below waits
-            // for its loads once per trip, four dependent round trips to random rows of the master; same sums in the same order
-            float4 x0[4], x1[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { x0[i] = a0[lane + 64 * i]; x1[i] = a1[lane + 64 * i]; b[i] = qv[lane + 64 * i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s0 = fmaf(x0[i].x, b[i].x, s0); s0 = fmaf(x0[i].y, b[i].y, s0); s0 = fmaf(x0[i].z, b[i].z, s0); s0 = fmaf(x0[i].w, b[i].w, s0);
-                s1 = fmaf(x1[i].x, b[i].x, s1); s1 = fmaf(x1[i].y, b[i].y, s1); s1 = fmaf(x1[i].z, b[i].z, s1); s1 = fmaf(x1[i].w, b[i].w, s1);
-            }
-        } else
         for (int v = lane; v < nvec; v += 64) {
             const float4 x0 = a0[v], x1 = a1[v], b = qv[v];
             s0 = fmaf(x0.x, b.x, s0); s0 = fmaf(x0.y, b.y, s0); s0 = fmaf(x0.z, b.z, s0); s0 = fmaf(x0.w, b.w, s0);
@@ -101,21 +89,6 @@ __device__ __forceinline__ void estimate_range_bf16(const uint64_t* in, uint64_t
             a[i] = reinterpret_cast<const uint4*>(scan16 + (size_t)r[i] * pitch);
             acc[i] = 0.f;
         }
-        if (nvec == 128) {
-            // (r04c) K = 1024: both 16-byte steps of a lane for all NR rows in flight at once (eight loads, one round trip)
-            uint4 x[2][NR];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < NR; ++i) x[h][i] = a[i][lane + 64 * h];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int v = lane + 64 * h;
-                const float4 b0 = qv[2 * v], b1 = qv[2 * v + 1];
-#pragma unroll
-                for (int i = 0; i < NR; ++i) acc[i] = dot8_bf16(x[h][i], b0, b1, acc[i]);
-            }
-        } else
         for (int v = lane; v < nvec; v += 64) {
             uint4 x[NR];
 #pragma unroll
@@ -159,30 +132,17 @@ __global__ __launch_bounds__(1024) void select_i8_kernel(SelArgs sa) {
     }
     __syncthreads();
     // ---- gather: one wave per chunk list; "chunk" n_chunks is the query's overflow pool (what found its list full)
-    // (r04c: four lists of a wave at a time -- their counts in one round trip, then their keys; one list at a time was two dependent
-    // round trips per list, four or five lists per wave)
-    const int nw = (int)(blockDim.x >> 6);
-    for (int c0 = wave; c0 <= p.n_chunks; c0 += 4 * nw) {
-        int cn[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j * nw;
-            cn[j] = c > p.n_chunks ? 0 : c == p.n_chunks ? p.ovf_cnt[q] : min(p.cand_cnt[(size_t)c * p.b_pad + q], CAND_CAP);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j * nw;
-            const bool pool = c == p.n_chunks;
-            int n = cn[j];
-            if (pool && n > I8_OVF_CAP) { n = I8_OVF_CAP; if (lane == 0) s_over = 1; }       // the pool overflowed too: rows were dropped
-            if (n <= 0) continue;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_total, n);
-            base = __shfl(base, 0, 64);
-            const uint64_t* list = pool ? p.ovf + (size_t)q * I8_OVF_CAP : p.cand + ((size_t)c * p.b_pad + q) * CAND_CAP;
-            for (int i = lane; i < n; i += 64)
-                if (base + i < KEY_CAP) keys[base + i] = list[i];
-        }
+    for (int c = wave; c <= p.n_chunks; c += (int)(blockDim.x >> 6)) {
+        const bool pool = c == p.n_chunks;
+        int n = pool ? p.ovf_cnt[q] : min(p.cand_cnt[(size_t)c * p.b_pad + q], CAND_CAP);
+        if (pool && n > I8_OVF_CAP) { n = I8_OVF_CAP; if (lane == 0) s_over = 1; }       // the pool overflowed too: rows were dropped
+        if (n <= 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_total, n);
+        base = __shfl(base, 0, 64);
+        const uint64_t* list = pool ? p.ovf + (size_t)q * I8_OVF_CAP : p.cand + ((size_t)c * p.b_pad + q) * CAND_CAP;
+        for (int i = lane; i < n; i += 64)
+            if (base + i < KEY_CAP) keys[base + i] = list[i];
     }
     __syncthreads();
     int N = s_total;
